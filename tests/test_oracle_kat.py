@@ -1,0 +1,215 @@
+"""Analytic known-answer tests for the CPU oracle.
+
+These are librosa-independent: each case has a closed-form answer, so they pin
+the oracle's restatement of the librosa 0.11.0 semantics the reference calls
+(audio_feature_extraction_toolkit/core/feature_extractor.py:69,72,127-138,164)
+as far as it can be pinned without librosa ("parity unpinned", see
+oracle/cpu_ref.py)."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as R
+
+
+def test_preemphasis_constant_signal():
+    # constant c: out[0] = 3c - c = 2c (zi = 2*y0 - y1), out[n>0] = c - 0.97c
+    c = np.float32(0.25)
+    y = np.full(1000, c, dtype=np.float32)
+    out = R.preemphasis(y, 0.97)
+    assert out.dtype == np.float32
+    assert out[0] == pytest.approx(2 * c, rel=1e-6)
+    np.testing.assert_allclose(out[1:], c - np.float32(0.97) * c, rtol=1e-5)
+
+
+def test_preemphasis_matches_fir_definition():
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(4096).astype(np.float32)
+    out = R.preemphasis(y, 0.97)
+    b1 = np.float32(-0.97)
+    exp = y.copy()
+    exp[1:] = y[1:] + b1 * y[:-1]          # float32, product rounded then added
+    exp[0] = (np.float32(2) * y[0] - y[1]) + y[0]
+    np.testing.assert_array_equal(out, exp)  # bit-exact: lfilter rounds the same way
+
+
+def test_rms_constant_signal_interior_frames():
+    c = 0.3
+    y = np.full(8192, c, dtype=np.float32)
+    r = R.rms(y, 1024, 256)[0]
+    assert r.shape == (1 + 8192 // 256,)
+    np.testing.assert_allclose(r[2:-2], c, rtol=1e-6)
+    # first frame sees half zeros (center pad): rms = c/sqrt(2)
+    assert r[0] == pytest.approx(c / np.sqrt(2), rel=1e-6)
+
+
+def test_stft_unit_impulse_flat_spectrum():
+    n_fft, hop = 1024, 256
+    y = np.zeros(4096, dtype=np.float32)
+    n0 = 2048 + 100
+    y[n0] = 1.0
+    D = R.stft(y, n_fft, hop, "hamming")
+    w = R.get_window("hamming", n_fft)
+    # frame t covers padded[t*hop : t*hop+n_fft] = y[t*hop - 512 : ...]
+    t = 8
+    pos = n0 - (t * hop - n_fft // 2)
+    assert 0 <= pos < n_fft
+    np.testing.assert_allclose(np.abs(D[:, t]) ** 2, w[pos] ** 2, rtol=1e-5)
+
+
+def test_stft_bin_centred_sinusoid_peak():
+    n_fft, hop, sr = 1024, 256, 22050
+    k0, A = 100, 0.4
+    n = np.arange(16384)
+    y = (A * np.cos(2 * np.pi * k0 * n / n_fft)).astype(np.float32)
+    D = R.stft(y, n_fft, hop, "hamming")
+    w = R.get_window("hamming", n_fft)
+    t = 20  # interior frame
+    assert np.abs(D[k0, t]) ** 2 == pytest.approx((A * w.sum() / 2) ** 2, rel=1e-4)
+    assert np.argmax(np.abs(D[:, t])) == k0
+
+
+def test_hamming_is_periodic():
+    w = R.get_window("hamming", 1024)
+    n = np.arange(1024)
+    np.testing.assert_allclose(w, 0.54 - 0.46 * np.cos(2 * np.pi * n / 1024), atol=1e-14)
+    w = R.get_window("hann", 512)
+    n = np.arange(512)
+    np.testing.assert_allclose(w, 0.5 - 0.5 * np.cos(2 * np.pi * n / 512), atol=1e-14)
+
+
+@pytest.mark.parametrize("sr,n_fft,nnz", [(22050, 1024, 1008), (16000, 512, 504), (44100, 2048, 2014)])
+def test_mel_filterbank_structure(sr, n_fft, nnz):
+    W = R.mel_filterbank(sr, n_fft, 128)
+    assert W.shape == (128, n_fft // 2 + 1) and W.dtype == np.float32
+    assert np.count_nonzero(W) == nnz
+    assert (W >= 0).all() and (np.count_nonzero(W, axis=1) > 0).all()
+    # every bin feeds at most two (adjacent) filters
+    per_bin = [np.flatnonzero(W[:, k]) for k in range(W.shape[1])]
+    assert all(len(p) <= 2 and (len(p) < 2 or p[1] - p[0] == 1) for p in per_bin)
+    # Slaney area normalisation: integral of each (wide) triangle ~ 1
+    df = sr / n_fft
+    area = W[96:].sum(axis=1) * df
+    np.testing.assert_allclose(area, 1.0, rtol=0.15)
+
+
+def test_mel_scale_breakpoints():
+    f = R.mel_frequencies(130, 0.0, 11025.0)
+    assert f[0] == 0.0 and f[-1] == pytest.approx(11025.0)
+    # linear below 1 kHz with 200/3 Hz per mel
+    mels = np.linspace(0, R._hz_to_mel(11025.0), 130)
+    lin = mels < 15
+    np.testing.assert_allclose(f[lin], mels[lin] * 200.0 / 3, rtol=1e-12)
+    assert R._hz_to_mel(1000.0) == pytest.approx(15.0)
+    assert R._mel_to_hz(R._hz_to_mel(6400.0)) == pytest.approx(6400.0)
+    assert R._hz_to_mel(6400.0) == pytest.approx(15.0 + 27.0)
+
+
+def test_power_to_db_global_clamp():
+    S = np.array([[1.0, 1e-3], [1e-12, 1e-20]], dtype=np.float32)
+    L = R.power_to_db(S)
+    # max is 0 dB; floor is -80 dB (clip-global), amin floor would be -100
+    np.testing.assert_allclose(L, [[0.0, -30.0], [-80.0, -80.0]], atol=1e-4)
+    L2 = R.power_to_db(S, top_db=None)
+    np.testing.assert_allclose(L2, [[0.0, -30.0], [-100.0, -100.0]], atol=1e-4)
+
+
+def test_dct_of_constant_logmel_only_c0():
+    import scipy.fft
+    v, M = -37.5, 128
+    L = np.full((M, 5), v, dtype=np.float32)
+    C = scipy.fft.dct(L, axis=-2, type=2, norm="ortho")[:13]
+    np.testing.assert_allclose(C[0], np.sqrt(M) * v, rtol=1e-6)
+    np.testing.assert_allclose(C[1:], 0.0, atol=1e-3)
+
+
+def test_delta_linear_ramp_and_quadratic():
+    t = np.arange(50, dtype=np.float64)
+    ramp = (0.7 * t + 3.0)[None, :].astype(np.float32)
+    d = R.delta(ramp)
+    np.testing.assert_allclose(d, 0.7, rtol=1e-5)             # incl. both edges
+    quad = (0.25 * t * t - 2 * t + 1)[None, :].astype(np.float32)
+    d2 = R.delta(quad, order=2)
+    np.testing.assert_allclose(d2, 0.5, rtol=1e-3)
+
+
+def test_delta_edge_rule_and_taps():
+    # interior: correlation taps [-4..4]/60 and [28,7,-8,-17,-20,-17,-8,7,28]/462;
+    # 'interp' edges replicate frame 4 / frame T-5
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, 40))
+    d1, d2 = R.delta(x), R.delta(x, order=2)
+    c1 = np.arange(-4, 5) / 60.0
+    c2 = np.array([28, 7, -8, -17, -20, -17, -8, 7, 28]) / 462.0
+    for t in range(4, 36):
+        np.testing.assert_allclose(d1[:, t], x[:, t - 4:t + 5] @ c1, atol=1e-12)
+        np.testing.assert_allclose(d2[:, t], x[:, t - 4:t + 5] @ c2, atol=1e-12)
+    for t in range(4):
+        np.testing.assert_allclose(d1[:, t], d1[:, 4], atol=1e-12)
+        np.testing.assert_allclose(d2[:, t], d2[:, 4], atol=1e-12)
+        np.testing.assert_allclose(d1[:, 39 - t], d1[:, 35], atol=1e-12)
+        np.testing.assert_allclose(d2[:, 39 - t], d2[:, 35], atol=1e-12)
+
+
+def test_delta_needs_nine_frames():
+    with pytest.raises(ValueError):
+        R.delta(np.zeros((13, 8), dtype=np.float32))
+
+
+def test_all_zero_clip_is_not_trimmed():
+    # the loudest frame is always 0 dB re itself, so trim can never return an empty
+    # signal: for digital silence every frame has db = -100 - (-100) = 0 > -30.
+    # (SURVEY.md section 7 guessed "empty -> raises"; the amin floor says otherwise.)
+    y = np.zeros(22050, dtype=np.float32)
+    yt, (s, e) = R.trim(y)
+    assert (s, e) == (0, 22050) and yt.size == 22050
+    out = R.extract_stats(y)
+    assert out["mfcc_mean"][0] == pytest.approx(-100.0 * np.sqrt(128), rel=1e-6)
+    np.testing.assert_allclose(out["mfcc_mean"][1:], 0.0, atol=1e-3)
+    assert out["energy_mean"] == 0.0 and out["energy_range"] == 0.0
+
+
+def test_too_short_clip_raises():
+    # T = 1 + N'//hop < 9 frames -> librosa.feature.delta raises (width 9 > T)
+    rng = np.random.default_rng(0)
+    y = (0.1 * rng.standard_normal(7 * 256 + 10)).astype(np.float32)
+    with pytest.raises(ValueError):
+        R.extract_stats(y)
+    y = (0.1 * rng.standard_normal(8 * 256)).astype(np.float32)   # T = 9
+    R.extract_stats(y)
+
+
+def test_trim_bounds_on_padded_tone():
+    sr = 22050
+    y = np.zeros(3 * sr, dtype=np.float32)
+    n = np.arange(sr)
+    y[sr:2 * sr] = 0.5 * np.sin(2 * np.pi * 440 * n / sr)
+    _, (s, e) = R.trim(y, top_db=30)
+    # non-silent frames are those overlapping the tone enough; bounds are hop (512) multiples
+    assert s % 512 == 0 and (e % 512 == 0 or e == y.size)
+    assert sr - 1024 <= s <= sr and 2 * sr <= e <= 2 * sr + 1536
+
+
+def test_nonfinite_audio_raises():
+    y = np.ones(4096, dtype=np.float32)
+    y[100] = np.nan
+    with pytest.raises(ValueError):
+        R.extract_stats(y)
+
+
+def test_frame_count_matches_table():
+    # SURVEY.md section 8 size table
+    assert R.frame_count(110250, 256) == 431
+    assert R.frame_count(220500, 256) == 862
+    assert R.frame_count(160000, 128) == 1251
+    assert R.frame_count(441000, 512) == 862
+
+
+def test_float32_tracks_float64_truth():
+    from audio_feature_extraction_amd.synth import make_clip
+    y = make_clip(3, 22050, 2.0)
+    a = R.extract_stats(y, return_frames=True)
+    b = R.extract_stats(y, dtype=np.float64, return_frames=True)
+    assert a["mfcc"].dtype == np.float32 and b["mfcc"].dtype == np.float64
+    scale = np.abs(b["mfcc"]).max(axis=1, keepdims=True)
+    assert (np.abs(a["mfcc"] - b["mfcc"]) / scale).max() < 2e-5
+    np.testing.assert_allclose(a["rms"], b["rms"], rtol=2e-6)
