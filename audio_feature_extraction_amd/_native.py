@@ -1,0 +1,253 @@
+"""ctypes binding of libafx.so (include/afx.h).  The product path has no CPU
+fallback: if the HIP library is missing or no GPU is visible, calls fail loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libafx.so")
+
+AFX_OK = 0
+CLIP_OK, CLIP_TOO_SHORT, CLIP_NONFINITE = 0, 1, 2
+WINDOW_HAMMING, WINDOW_HANN = 0, 1
+FMT_F32, FMT_S16 = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+FLAG_PREEMPH, FLAG_TRIM = 1, 2
+K_NAMES = ("trim_blocks", "trim_decide", "frames", "dct", "stats")
+K_FRAMES = 2
+
+# every symbol include/afx.h declares
+SYMBOLS = (
+    "afx_version", "afx_device_count", "afx_last_error", "afx_init", "afx_destroy",
+    "afx_malloc", "afx_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
+    "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables",
+    "afx_extract_batch", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings",
+)
+
+
+class AfxError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("sr", C.c_int32), ("n_fft", C.c_int32), ("hop", C.c_int32), ("n_mfcc", C.c_int32),
+        ("n_mels", C.c_int32), ("window", C.c_int32), ("preemph", C.c_float),
+        ("trim_top_db", C.c_float), ("trim_frame", C.c_int32), ("trim_hop", C.c_int32),
+        ("top_db", C.c_float), ("amin", C.c_float), ("delta_width", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> C.CDLL:
+    """Loads libafx.so once; raises AfxError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise AfxError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C audio_feature_extraction_amd/csrc` (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64p, f32p, i32p = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.afx_version.restype = i32
+        L.afx_device_count.restype = i32
+        L.afx_last_error.restype = C.c_char_p
+        L.afx_init.argtypes = [i32, C.POINTER(vp)]
+        L.afx_destroy.argtypes = [vp]; L.afx_destroy.restype = None
+        L.afx_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.afx_free.argtypes = [vp, vp]
+        L.afx_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+        L.afx_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+        L.afx_synchronize.argtypes = [vp]
+        L.afx_default_params.argtypes = [C.POINTER(Params)]; L.afx_default_params.restype = None
+        L.afx_plan_create.argtypes = [vp, C.POINTER(Params), C.POINTER(vp)]
+        L.afx_plan_destroy.argtypes = [vp]; L.afx_plan_destroy.restype = None
+        L.afx_build_tables.argtypes = [C.POINTER(Params), vp, vp, vp]
+        L.afx_extract_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+        L.afx_preprocess.argtypes = [vp, vp, C.c_int64, vp, i64p, i64p, i32p]
+        L.afx_plan_set_timing.argtypes = [vp, i32]
+        L.afx_plan_get_timings.argtypes = [vp, vp, vp, i32]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != AFX_OK:
+        msg = lib().afx_last_error().decode("utf-8", "replace")
+        if rc == -5:
+            raise NotImplementedError(f"{what}: {msg}")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise AfxError(f"{what} failed ({rc}): {msg}")
+
+
+def device_count() -> int:
+    return int(lib().afx_device_count())
+
+
+def make_params(sr=22050, n_fft=1024, hop=256, n_mfcc=13, n_mels=128, window="hamming",
+                preemph=0.97) -> Params:
+    p = Params()
+    lib().afx_default_params(C.byref(p))
+    p.sr, p.n_fft, p.hop, p.n_mfcc, p.n_mels = int(sr), int(n_fft), int(hop), int(n_mfcc), int(n_mels)
+    wl = {"hamming": WINDOW_HAMMING, "hann": WINDOW_HANN}
+    if window not in wl:
+        raise ValueError(f"unsupported window {window!r} (hamming, hann)")
+    p.window = wl[window]
+    p.preemph = float(preemph)
+    return p
+
+
+def build_tables(p: Params):
+    """Host-only: (window[n_fft], mel[n_mels, n_fft/2+1], dct[n_mfcc, n_mels]) as uploaded by a plan."""
+    nb = p.n_fft // 2 + 1
+    win = np.empty(p.n_fft, np.float32)
+    mel = np.empty((p.n_mels, nb), np.float32)
+    dct = np.empty((p.n_mfcc, p.n_mels), np.float32)
+    _check(lib().afx_build_tables(C.byref(p), win.ctypes.data, mel.ctypes.data, dct.ctypes.data), "afx_build_tables")
+    return win, mel, dct
+
+
+class DeviceBuffer:
+    """HBM allocation owned by a Context (for device-resident batches)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        ptr = C.c_void_p()
+        _check(lib().afx_malloc(ctx.handle, self.nbytes, C.byref(ptr)), "afx_malloc")
+        self.ptr = ptr.value
+
+    def upload(self, arr: np.ndarray, byte_offset: int = 0):
+        arr = np.ascontiguousarray(arr)
+        assert byte_offset + arr.nbytes <= self.nbytes
+        _check(lib().afx_memcpy_h2d(self.ctx.handle, self.ptr + byte_offset, arr.ctypes.data, arr.nbytes), "afx_memcpy_h2d")
+
+    def free(self):
+        if self.ptr:
+            lib().afx_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One HIP device + stream.  Not thread-safe: one per worker thread."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        _check(lib().afx_init(int(device), C.byref(h)), f"afx_init(device={device})")
+        self.handle, self.device = h, int(device)
+
+    def close(self):
+        if self.handle:
+            lib().afx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    def __init__(self, ctx: Context, params: Params):
+        self.ctx, self.params = ctx, params
+        h = C.c_void_p()
+        _check(lib().afx_plan_create(ctx.handle, C.byref(params), C.byref(h)), "afx_plan_create")
+        self.handle = h
+        self.n_stats = 4 * params.n_mfcc + 3
+
+    def close(self):
+        if self.handle:
+            lib().afx_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_timing(self, on: bool):
+        _check(lib().afx_plan_set_timing(self.handle, 1 if on else 0), "afx_plan_set_timing")
+
+    def timings(self, reset: bool = True):
+        ms = np.zeros(len(K_NAMES), np.float32)
+        n = np.zeros(len(K_NAMES), np.int32)
+        _check(lib().afx_plan_get_timings(self.handle, ms.ctypes.data, n.ctypes.data, 1 if reset else 0), "afx_plan_get_timings")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(K_NAMES)}
+
+    def extract_batch(self, samples, offsets, lengths, flags=FLAG_PREEMPH | FLAG_TRIM,
+                      fmt=FMT_F32, want_frames: bool = False, out=None):
+        """samples: numpy array (host) or DeviceBuffer/int device pointer.  Returns a dict with
+        stats [n, 4K+3], status [n], trim [n, 2], nframes [n] (and frames list when asked)."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        lengths = np.ascontiguousarray(lengths, np.int64)
+        n = int(offsets.shape[0])
+        K, hop = self.params.n_mfcc, self.params.hop
+        if out is None:
+            out = {
+                "stats": np.zeros((n, self.n_stats), np.float32),
+                "status": np.zeros(n, np.int32),
+                "trim": np.zeros((n, 2), np.int64),
+                "nframes": np.zeros(n, np.int32),
+            }
+        if isinstance(samples, np.ndarray):
+            want = np.int16 if fmt == FMT_S16 else np.float32
+            if samples.dtype != want or not samples.flags.c_contiguous:
+                raise ValueError(f"samples must be C-contiguous {want.__name__}")
+            if n and int((offsets + lengths).max()) > samples.size:
+                raise ValueError("clip extends past the sample buffer")
+            sptr, kind = samples.ctypes.data, MEM_HOST
+        else:
+            sptr = samples.ptr if isinstance(samples, DeviceBuffer) else int(samples)
+            kind = MEM_DEVICE
+        fptr = foffs_ptr = None
+        frames = foffs = None
+        if want_frames:
+            tmax = 1 + lengths // hop
+            rows = 3 * K + 1
+            foffs = np.zeros(n, np.int64)
+            if n:
+                foffs[1:] = np.cumsum(rows * tmax)[:-1]
+            frames = np.zeros(int((rows * tmax).sum()) if n else 0, np.float32)
+            fptr, foffs_ptr = frames.ctypes.data, foffs.ctypes.data
+        rc = lib().afx_extract_batch(
+            self.handle, sptr, int(fmt), kind, offsets.ctypes.data, lengths.ctypes.data, n, int(flags),
+            out["stats"].ctypes.data, out["status"].ctypes.data, out["trim"].ctypes.data,
+            out["nframes"].ctypes.data, fptr, foffs_ptr)
+        _check(rc, "afx_extract_batch")
+        if want_frames:
+            res = []
+            for i in range(n):
+                tm, T = int(1 + lengths[i] // hop), int(out["nframes"][i])
+                blk = frames[foffs[i]: foffs[i] + (3 * K + 1) * tm].reshape(3 * K + 1, tm)[:, :T]
+                res.append({"mfcc": blk[:K].copy(), "mfcc_delta": blk[K:2 * K].copy(),
+                            "mfcc_delta2": blk[2 * K:3 * K].copy(), "rms": blk[3 * K:].copy()})
+            out["frames"] = res
+        return out
+
+    def preprocess(self, y: np.ndarray):
+        y = np.ascontiguousarray(y, np.float32)
+        out = np.empty_like(y)
+        s, e, st = C.c_int64(), C.c_int64(), C.c_int32()
+        _check(lib().afx_preprocess(self.handle, y.ctypes.data, y.size, out.ctypes.data,
+                                    C.byref(s), C.byref(e), C.byref(st)), "afx_preprocess")
+        return out, int(s.value), int(e.value), int(st.value)

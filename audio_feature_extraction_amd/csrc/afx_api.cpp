@@ -1,0 +1,433 @@
+// C-ABI layer of libafx.so: contexts, plans, workspace management and the
+// batch entry point that strings the five kernels together on one HIP stream.
+// See include/afx.h for the contract and the reference call sites replaced.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "afx_device.h"
+#include "afx_internal.h"
+
+namespace afx {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace afx
+
+using namespace afx;
+
+struct afx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+};
+
+struct afx_plan {
+  afx_ctx* ctx = nullptr;
+  afx_params p{};
+  KParams kp{};
+  HostTables ht;
+  DevTables dt{};
+  std::vector<void*> table_allocs;
+  DevBuf samples, clips, info, blocks, bsum, logmel, rms, mfcc, stats, frames, frame_offs;
+  // cached per-batch descriptors
+  std::vector<int64_t> c_off, c_len;
+  std::vector<ClipDesc> h_clips;
+  int nblocks = 0, max_tblocks = 0, max_tmax = 0;
+  int64_t total_tpad = 0, total_tblk = 0;
+  std::vector<ClipInfo> h_info;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[AFX_K_COUNT][2] = {};
+  bool ev_ready = false;
+  double ms_sum[AFX_K_COUNT] = {};
+  int32_t launches[AFX_K_COUNT] = {};
+  int n_cu = 256;
+};
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e__));                   \
+      return AFX_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+static int ensure(DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return AFX_OK;
+  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+    b.p = nullptr;
+    return e == hipErrorOutOfMemory ? AFX_ERR_NOMEM : AFX_ERR_HIP;
+  }
+  b.cap = want;
+  return AFX_OK;
+}
+
+static void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr; b.cap = 0;
+}
+
+extern "C" int afx_version(void) { return AFX_VERSION; }
+
+extern "C" const char* afx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int afx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int afx_init(int device, afx_ctx** out) {
+  if (!out) { set_error("afx_init: null out"); return AFX_ERR_INVALID; }
+  *out = nullptr;
+  int n = afx_device_count();
+  if (n <= 0) { set_error("no HIP device visible"); return AFX_ERR_NO_DEVICE; }
+  if (device < 0 || device >= n) { set_error("device index out of range"); return AFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(device));
+  afx_ctx* c = new afx_ctx();
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e)); return AFX_ERR_HIP; }
+  *out = c;
+  return AFX_OK;
+}
+
+extern "C" void afx_destroy(afx_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int afx_malloc(afx_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out) { set_error("afx_malloc: null argument"); return AFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+  if (e != hipSuccess) { set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); return e == hipErrorOutOfMemory ? AFX_ERR_NOMEM : AFX_ERR_HIP; }
+  return AFX_OK;
+}
+
+extern "C" int afx_free(afx_ctx* ctx, void* d) {
+  if (!ctx) { set_error("afx_free: null ctx"); return AFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (d) HIP_TRY(hipFree(d));
+  return AFX_OK;
+}
+
+extern "C" int afx_memcpy_h2d(afx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (!dst && bytes) || (!src && bytes)) { set_error("afx_memcpy_h2d: null argument"); return AFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+
+extern "C" int afx_memcpy_d2h(afx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (!dst && bytes) || (!src && bytes)) { set_error("afx_memcpy_d2h: null argument"); return AFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+
+extern "C" int afx_synchronize(afx_ctx* ctx) {
+  if (!ctx) { set_error("afx_synchronize: null ctx"); return AFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return AFX_OK;
+}
+
+template <typename T>
+static int upload(afx_plan* pl, const T* host, size_t count, const T** dev) {
+  void* d = nullptr;
+  size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  hipError_t e = hipMalloc(&d, bytes);
+  if (e != hipSuccess) { set_error(std::string("hipMalloc(table): ") + hipGetErrorString(e)); return AFX_ERR_HIP; }
+  pl->table_allocs.push_back(d);
+  HIP_TRY(hipMemset(d, 0, bytes));
+  if (count) HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+  *dev = (const T*)d;
+  return AFX_OK;
+}
+
+static int kmax_bucket(int K) { return K <= 16 ? 16 : K <= 32 ? 32 : K <= 64 ? 64 : 128; }
+
+extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out) {
+  if (!ctx || !p || !out) { set_error("afx_plan_create: null argument"); return AFX_ERR_INVALID; }
+  *out = nullptr;
+  std::string msg;
+  int st = validate_params(*p, msg);
+  if (st != AFX_OK) { set_error(msg); return st; }
+  if (p->n_fft > 2048) { set_error("frame_length > 2048 is not supported by the LDS-resident FFT"); return AFX_ERR_UNSUPPORTED; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  afx_plan* pl = new afx_plan();
+  pl->ctx = ctx; pl->p = *p;
+  build_host_tables(*p, pl->ht);
+  const size_t lds = frames_lds_bytes(p->n_fft, p->hop, (int)pl->ht.mel.taps.size(), p->n_mels);
+  if (lds == 0 || lds > 160 * 1024) {
+    delete pl;
+    set_error("frame_length/hop_length combination needs more than 160 KiB of LDS per workgroup (hop too large)");
+    return AFX_ERR_UNSUPPORTED;
+  }
+  KParams& kp = pl->kp;
+  kp.n_fft = p->n_fft; kp.hop = p->hop; kp.n_mels = p->n_mels; kp.n_mfcc = p->n_mfcc;
+  kp.trim_frame = p->trim_frame; kp.trim_hop = p->trim_hop;
+  kp.preemph_b1 = (float)(-(double)p->preemph);     // np.asarray([1.0, -coef], dtype=float32)
+  kp.trim_top_db = p->trim_top_db; kp.top_db = p->top_db; kp.amin = p->amin;
+  kp.flags = 0; kp.fmt = AFX_FMT_F32;
+  int rc = AFX_OK;
+  const HostTables& t = pl->ht;
+  std::vector<float> dct_pad((size_t)kmax_bucket(p->n_mfcc) * p->n_mels, 0.f);
+  std::memcpy(dct_pad.data(), t.dct.data(), t.dct.size() * sizeof(float));
+  if ((rc = upload(pl, t.window.data(), t.window.size(), &pl->dt.window)) != AFX_OK ||
+      (rc = upload(pl, t.tw.data(), t.tw.size(), &pl->dt.tw)) != AFX_OK ||
+      (rc = upload(pl, t.post.data(), t.post.size(), &pl->dt.post)) != AFX_OK ||
+      (rc = upload(pl, t.mel.taps.data(), t.mel.taps.size(), &pl->dt.taps)) != AFX_OK ||
+      (rc = upload(pl, t.mel.k0.data(), t.mel.k0.size(), &pl->dt.mel_k0)) != AFX_OK ||
+      (rc = upload(pl, t.mel.ntap4.data(), t.mel.ntap4.size(), &pl->dt.mel_n4)) != AFX_OK ||
+      (rc = upload(pl, t.mel.woff.data(), t.mel.woff.size(), &pl->dt.mel_wo)) != AFX_OK ||
+      (rc = upload(pl, dct_pad.data(), dct_pad.size(), &pl->dt.dct)) != AFX_OK) {
+    afx_plan_destroy(pl);
+    return rc;
+  }
+  pl->dt.ntaps = (int32_t)t.mel.taps.size();
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+    pl->n_cu = prop.multiProcessorCount;
+  *out = pl;
+  return AFX_OK;
+}
+
+extern "C" void afx_plan_destroy(afx_plan* pl) {
+  if (!pl) return;
+  (void)hipSetDevice(pl->ctx->device);
+  for (void* d : pl->table_allocs) (void)hipFree(d);
+  release(pl->samples); release(pl->clips); release(pl->info); release(pl->blocks); release(pl->bsum);
+  release(pl->logmel); release(pl->rms); release(pl->mfcc); release(pl->stats); release(pl->frames);
+  release(pl->frame_offs);
+  if (pl->ev_ready)
+    for (int k = 0; k < AFX_K_COUNT; ++k) { (void)hipEventDestroy(pl->ev[k][0]); (void)hipEventDestroy(pl->ev[k][1]); }
+  delete pl;
+}
+
+extern "C" int afx_plan_set_timing(afx_plan* pl, int enable) {
+  if (!pl) { set_error("afx_plan_set_timing: null plan"); return AFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(pl->ctx->device));
+  if (enable && !pl->ev_ready) {
+    for (int k = 0; k < AFX_K_COUNT; ++k) { HIP_TRY(hipEventCreate(&pl->ev[k][0])); HIP_TRY(hipEventCreate(&pl->ev[k][1])); }
+    pl->ev_ready = true;
+  }
+  pl->timing = enable != 0;
+  return AFX_OK;
+}
+
+extern "C" int afx_plan_get_timings(afx_plan* pl, float* ms, int32_t* launches, int reset) {
+  if (!pl) { set_error("afx_plan_get_timings: null plan"); return AFX_ERR_INVALID; }
+  for (int k = 0; k < AFX_K_COUNT; ++k) {
+    if (ms) ms[k] = (float)pl->ms_sum[k];
+    if (launches) launches[k] = pl->launches[k];
+    if (reset) { pl->ms_sum[k] = 0.0; pl->launches[k] = 0; }
+  }
+  return AFX_OK;
+}
+
+// Builds (or reuses) the per-clip descriptors and the k_frames block list.
+static int prepare_descriptors(afx_plan* pl, const int64_t* offsets, const int64_t* lengths, int n) {
+  const bool same = (int)pl->c_len.size() == n &&
+                    std::memcmp(pl->c_len.data(), lengths, n * sizeof(int64_t)) == 0 &&
+                    std::memcmp(pl->c_off.data(), offsets, n * sizeof(int64_t)) == 0;
+  if (same) return AFX_OK;
+  const int hop = pl->p.hop, th = pl->p.trim_hop;
+  pl->h_clips.resize(n);
+  int64_t fb = 0, tb = 0;
+  int max_tb = 0, max_tm = 0;
+  std::vector<int2> blocks;
+  for (int i = 0; i < n; ++i) {
+    if (lengths[i] < 0 || offsets[i] < 0) { set_error("negative clip offset/length"); return AFX_ERR_INVALID; }
+    if (lengths[i] / hop > (int64_t)1 << 30) { set_error("clip too long"); return AFX_ERR_INVALID; }
+    ClipDesc& c = pl->h_clips[i];
+    c.off = offsets[i]; c.len = lengths[i];
+    c.tmax = (int32_t)(1 + lengths[i] / hop);
+    c.tpad = (c.tmax + kFramesPerBlock - 1) / kFramesPerBlock * kFramesPerBlock;
+    c.frame_base = fb; c.tblk_base = tb;
+    fb += c.tpad;
+    const int64_t ntb = (lengths[i] + th - 1) / th;
+    tb += ntb;
+    max_tb = std::max<int>(max_tb, (int)ntb);
+    max_tm = std::max<int>(max_tm, c.tmax);
+    for (int b = 0; b < c.tpad / kFramesPerBlock; ++b) blocks.push_back(make_int2(i, b));
+  }
+  pl->total_tpad = fb; pl->total_tblk = tb; pl->max_tblocks = std::max(max_tb, 1); pl->max_tmax = max_tm;
+  pl->nblocks = (int)blocks.size();
+  int rc;
+  if ((rc = ensure(pl->clips, n * sizeof(ClipDesc))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->blocks, std::max<size_t>(blocks.size(), 1) * sizeof(int2))) != AFX_OK) return rc;
+  hipStream_t s = pl->ctx->stream;
+  HIP_TRY(hipMemcpyAsync(pl->clips.p, pl->h_clips.data(), n * sizeof(ClipDesc), hipMemcpyHostToDevice, s));
+  if (!blocks.empty())
+    HIP_TRY(hipMemcpyAsync(pl->blocks.p, blocks.data(), blocks.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));   // `blocks` is a local; descriptors change rarely
+  pl->c_off.assign(offsets, offsets + n);
+  pl->c_len.assign(lengths, lengths + n);
+  return AFX_OK;
+}
+
+#define TIMED(slot, call)                                                      \
+  do {                                                                         \
+    if (pl->timing) HIP_TRY(hipEventRecord(pl->ev[slot][0], s));               \
+    HIP_TRY(call);                                                             \
+    if (pl->timing) { HIP_TRY(hipEventRecord(pl->ev[slot][1], s)); pl->launches[slot]++; } \
+  } while (0)
+
+static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kind,
+                         const int64_t* offsets, const int64_t* lengths, int n, int flags,
+                         float* out_stats, int32_t* out_status, int64_t* out_trim, int32_t* out_nframes,
+                         float* out_frames, const int64_t* frame_offsets) {
+  hipStream_t s = pl->ctx->stream;
+  const int K = pl->p.n_mfcc, M = pl->p.n_mels;
+  const int nstat = 4 * K + 3;
+  int rc;
+  if ((rc = prepare_descriptors(pl, offsets, lengths, n)) != AFX_OK) return rc;
+
+  const void* d_samples = samples;
+  const size_t esz = fmt == AFX_FMT_S16 ? 2 : 4;
+  if (mem_kind == AFX_MEM_HOST) {
+    int64_t hi = 0;
+    for (int i = 0; i < n; ++i) hi = std::max(hi, offsets[i] + lengths[i]);
+    if ((rc = ensure(pl->samples, (size_t)hi * esz + 16)) != AFX_OK) return rc;
+    if (hi > 0) HIP_TRY(hipMemcpyAsync(pl->samples.p, samples, (size_t)hi * esz, hipMemcpyHostToDevice, s));
+    d_samples = pl->samples.p;
+  }
+  if ((rc = ensure(pl->info, n * sizeof(ClipInfo))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->bsum, std::max<int64_t>(pl->total_tblk, 1) * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->logmel, (size_t)pl->total_tpad * M * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->rms, (size_t)pl->total_tpad * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->mfcc, (size_t)pl->total_tpad * K * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->stats, (size_t)n * nstat * sizeof(float))) != AFX_OK) return rc;
+  float* d_frames = nullptr;
+  size_t frames_floats = 0;
+  if (out_frames) {
+    if (!frame_offsets) { set_error("out_frames given without frame_offsets"); return AFX_ERR_INVALID; }
+    for (int i = 0; i < n; ++i)
+      frames_floats = std::max<size_t>(frames_floats, (size_t)frame_offsets[i] + (size_t)(3 * K + 1) * pl->h_clips[i].tmax);
+    if ((rc = ensure(pl->frames, frames_floats * sizeof(float))) != AFX_OK) return rc;
+    if ((rc = ensure(pl->frame_offs, n * sizeof(int64_t))) != AFX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(pl->frame_offs.p, frame_offsets, n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    d_frames = (float*)pl->frames.p;
+  }
+
+  KParams kp = pl->kp;
+  kp.flags = flags; kp.fmt = fmt;
+  const ClipDesc* d_clips = (const ClipDesc*)pl->clips.p;
+  ClipInfo* d_info = (ClipInfo*)pl->info.p;
+
+  HIP_TRY(hipMemsetAsync(d_info, 0, n * sizeof(ClipInfo), s));
+  TIMED(AFX_K_TRIM_BLOCKS, launch_trim_blocks(s, d_samples, d_clips, d_info, (float*)pl->bsum.p, n, pl->max_tblocks, kp));
+  TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, n, kp));
+  if (pl->nblocks > 0) {
+    const int grid = std::min(pl->nblocks, pl->n_cu * 2);
+    TIMED(AFX_K_FRAMES, launch_frames(s, d_samples, d_clips, d_info, (const int2*)pl->blocks.p, pl->nblocks,
+                                      pl->dt, kp, (float*)pl->logmel.p, (float*)pl->rms.p, grid));
+    TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax));
+  }
+  TIMED(AFX_K_STATS, launch_stats(s, d_clips, d_info, kp, (const float*)pl->mfcc.p, (const float*)pl->rms.p,
+                                  (float*)pl->stats.p, d_frames, (const int64_t*)pl->frame_offs.p, n));
+
+  pl->h_info.resize(n);
+  HIP_TRY(hipMemcpyAsync(out_stats, pl->stats.p, (size_t)n * nstat * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(pl->h_info.data(), d_info, n * sizeof(ClipInfo), hipMemcpyDeviceToHost, s));
+  if (out_frames && frames_floats)
+    HIP_TRY(hipMemcpyAsync(out_frames, d_frames, frames_floats * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (pl->timing) {
+    for (int k = 0; k < AFX_K_COUNT; ++k) {
+      if (pl->nblocks == 0 && (k == AFX_K_FRAMES || k == AFX_K_DCT)) continue;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, pl->ev[k][0], pl->ev[k][1]) == hipSuccess) pl->ms_sum[k] += ms;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    const ClipInfo& ci = pl->h_info[i];
+    out_status[i] = ci.status;
+    if (out_trim) { out_trim[2 * i] = ci.start; out_trim[2 * i + 1] = ci.end; }
+    if (out_nframes) out_nframes[i] = ci.T;
+  }
+  return AFX_OK;
+}
+
+extern "C" int afx_extract_batch(afx_plan* pl, const void* samples, int sample_fmt, int mem_kind,
+                                 const int64_t* offsets, const int64_t* lengths, int n_clips, int flags,
+                                 float* out_stats, int32_t* out_status, int64_t* out_trim,
+                                 int32_t* out_nframes, float* out_frames, const int64_t* frame_offsets) {
+  if (!pl || !offsets || !lengths || !out_stats || !out_status || n_clips < 0 || (!samples && n_clips > 0)) {
+    set_error("afx_extract_batch: null/invalid argument");
+    return AFX_ERR_INVALID;
+  }
+  if (sample_fmt != AFX_FMT_F32 && sample_fmt != AFX_FMT_S16) { set_error("unknown sample format"); return AFX_ERR_INVALID; }
+  if (mem_kind != AFX_MEM_HOST && mem_kind != AFX_MEM_DEVICE) { set_error("unknown mem_kind"); return AFX_ERR_INVALID; }
+  if (n_clips == 0) return AFX_OK;
+  HIP_TRY(hipSetDevice(pl->ctx->device));
+  const int nstat = 4 * pl->p.n_mfcc + 3;
+  const int kChunk = 32768;   // gridDim.y limit is 65535
+  for (int c0 = 0; c0 < n_clips; c0 += kChunk) {
+    const int n = std::min(kChunk, n_clips - c0);
+    int rc = extract_chunk(pl, samples, sample_fmt, mem_kind, offsets + c0, lengths + c0, n, flags,
+                           out_stats + (size_t)c0 * nstat, out_status + c0,
+                           out_trim ? out_trim + 2 * (size_t)c0 : nullptr,
+                           out_nframes ? out_nframes + c0 : nullptr, out_frames,
+                           frame_offsets ? frame_offsets + c0 : nullptr);
+    if (rc != AFX_OK) return rc;
+  }
+  return AFX_OK;
+}
+
+extern "C" int afx_preprocess(afx_plan* pl, const float* y, int64_t n, float* out_y,
+                              int64_t* start, int64_t* end, int32_t* status) {
+  if (!pl || !y || !out_y || !start || !end || !status || n < 0) {
+    set_error("afx_preprocess: null/invalid argument");
+    return AFX_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(pl->ctx->device));
+  hipStream_t s = pl->ctx->stream;
+  const int64_t off = 0;
+  int rc;
+  if ((rc = prepare_descriptors(pl, &off, &n, 1)) != AFX_OK) return rc;
+  if ((rc = ensure(pl->samples, (size_t)n * 4 + 16)) != AFX_OK) return rc;
+  if ((rc = ensure(pl->info, sizeof(ClipInfo))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->bsum, std::max<int64_t>(pl->total_tblk, 1) * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->logmel, (size_t)std::max<int64_t>(n, 1) * sizeof(float))) != AFX_OK) return rc;   // y_pre scratch
+  if (n > 0) HIP_TRY(hipMemcpyAsync(pl->samples.p, y, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  KParams kp = pl->kp;
+  kp.flags = AFX_FLAG_PREEMPH | AFX_FLAG_TRIM; kp.fmt = AFX_FMT_F32;
+  ClipInfo* d_info = (ClipInfo*)pl->info.p;
+  HIP_TRY(hipMemsetAsync(d_info, 0, sizeof(ClipInfo), s));
+  HIP_TRY(launch_trim_blocks(s, pl->samples.p, (const ClipDesc*)pl->clips.p, d_info, (float*)pl->bsum.p, 1, pl->max_tblocks, kp));
+  HIP_TRY(launch_trim_decide(s, (const ClipDesc*)pl->clips.p, d_info, (const float*)pl->bsum.p, 1, kp));
+  if (n > 0) {
+    HIP_TRY(launch_preemph(s, (const float*)pl->samples.p, (float*)pl->logmel.p, n, kp.preemph_b1));
+    HIP_TRY(hipMemcpyAsync(out_y, pl->logmel.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  }
+  ClipInfo ci{};
+  HIP_TRY(hipMemcpyAsync(&ci, d_info, sizeof(ClipInfo), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  // T is about the MFCC stage; preprocess_audio itself only fails on < 2 samples / non-finite input
+  *start = ci.start; *end = ci.end;
+  *status = (n < 2) ? AFX_CLIP_TOO_SHORT : (ci.nonfinite ? AFX_CLIP_NONFINITE : AFX_CLIP_OK);
+  return AFX_OK;
+}

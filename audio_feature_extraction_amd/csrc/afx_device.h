@@ -1,0 +1,71 @@
+// Device-visible structures and kernel launcher prototypes (host callable).
+#pragma once
+#include <cstdint>
+
+#include <hip/hip_runtime_api.h>
+
+#include "afx.h"
+
+namespace afx {
+
+constexpr int kFramesPerBlock = 16;   // F: frames one workgroup of k_frames owns
+constexpr int kWaves = 4;             // waves per workgroup in k_frames
+
+// Host-built, per clip.
+struct ClipDesc {
+  int64_t off;         // element offset of the clip in the packed sample buffer
+  int64_t len;         // N samples
+  int64_t frame_base;  // first padded frame slot of this clip (multiple of 16)
+  int64_t tblk_base;   // first trim-block slot of this clip
+  int32_t tmax;        // 1 + N / hop   (frame count before trim)
+  int32_t tpad;        // tmax rounded up to a multiple of 16
+};
+
+// Device-written, per clip (k_trim_decide), read by every later kernel.
+struct ClipInfo {
+  int64_t start, end;   // kept span [start, end) after trim (clip-relative)
+  int32_t T;            // frames = 1 + (end - start) / hop
+  int32_t status;       // afx_clip_status
+  uint32_t lmax_ord;    // order-preserving uint image of max log-mel (atomicMax)
+  uint32_t nonfinite;   // set by k_trim_blocks
+};
+
+struct DevTables {
+  const float* window;   // n_fft
+  const float* tw;       // n_fft/2 complex
+  const float* post;     // n_fft/2 complex
+  const float* taps;     // padded sparse mel taps
+  const int32_t* mel_k0;
+  const int32_t* mel_n4;
+  const int32_t* mel_wo;
+  const float* dct;      // n_mfcc x n_mels
+  int32_t ntaps;         // floats in taps
+};
+
+struct KParams {
+  int32_t n_fft, hop, n_mels, n_mfcc;
+  int32_t trim_frame, trim_hop;
+  float preemph_b1;      // float32(-coef)
+  float trim_top_db, top_db, amin;
+  int32_t flags;         // AFX_FLAG_*
+  int32_t fmt;           // AFX_FMT_*
+};
+
+// dynamic LDS bytes k_frames needs for (n_fft, hop, ntaps, n_mels); 0 if n_fft unsupported
+size_t frames_lds_bytes(int n_fft, int hop, int ntaps, int n_mels);
+
+hipError_t launch_trim_blocks(hipStream_t s, const void* samples, const ClipDesc* clips, ClipInfo* info,
+                              float* bsum, int n_clips, int max_tblocks, const KParams& kp);
+hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum,
+                              int n_clips, const KParams& kp);
+hipError_t launch_frames(hipStream_t s, const void* samples, const ClipDesc* clips, ClipInfo* info,
+                         const int2* blocks, int nblocks, const DevTables& tb, const KParams& kp,
+                         float* logmel, float* rms_rows, int grid);
+hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
+                      const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax);
+hipError_t launch_stats(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const KParams& kp,
+                        const float* mfcc, const float* rms_rows, float* stats, float* frames_out,
+                        const int64_t* frame_offsets, int n_clips);
+hipError_t launch_preemph(hipStream_t s, const float* y, float* out, int64_t n, float b1);
+
+}  // namespace afx

@@ -1,0 +1,138 @@
+// Host-side table construction for an afx_plan: what the reference gets from
+// scipy.signal.get_window('hamming', n, fftbins=True), librosa.filters.mel
+// (Slaney scale + Slaney area norm, float32 storage) and scipy.fft.dct(type=2,
+// norm='ortho') underneath librosa.feature.mfcc
+// (audio_feature_extraction_toolkit/core/feature_extractor.py:127-134).
+// Everything is evaluated in double and rounded where librosa rounds.
+#include <cmath>
+#include <cstring>
+
+#include "afx_internal.h"
+
+namespace afx {
+
+static const double kPi = 3.14159265358979323846;
+
+int validate_params(const afx_params& p, std::string& msg) {
+  auto bad = [&](const char* m) { msg = m; return (int)AFX_ERR_INVALID; };
+  if (p.sr <= 0) return bad("sr must be positive");
+  if (p.hop <= 0) return bad("hop_length must be positive");
+  if (p.n_mels <= 0 || p.n_mels > 512) return bad("n_mels must be in [1, 512]");
+  if (p.n_mels % 4 != 0) return bad("n_mels must be a multiple of 4");
+  if (p.n_mfcc <= 0 || p.n_mfcc > p.n_mels || p.n_mfcc > 128)
+    return bad("n_mfcc must be in [1, min(n_mels, 128)]");
+  if (p.window != AFX_WINDOW_HAMMING && p.window != AFX_WINDOW_HANN) return bad("unknown window");
+  if (p.delta_width != 9) return bad("delta_width must be 9 (librosa default used by the reference)");
+  if (p.trim_hop <= 0 || p.trim_frame <= 0 || p.trim_frame % p.trim_hop != 0 ||
+      (p.trim_frame / p.trim_hop) % 2 != 0)
+    return bad("trim_frame must be an even multiple of trim_hop");
+  if (!(p.amin > 0.f)) return bad("amin must be positive");
+  bool pow2 = p.n_fft > 0 && (p.n_fft & (p.n_fft - 1)) == 0;
+  if (!pow2 || p.n_fft < 256 || p.n_fft > 4096) {
+    msg = "frame_length must be a power of two in [256, 4096]";
+    return (int)AFX_ERR_UNSUPPORTED;
+  }
+  return AFX_OK;
+}
+
+// librosa.core.convert.hz_to_mel / mel_to_hz, htk=False
+static double hz_to_mel(double f) {
+  const double f_sp = 200.0 / 3, min_log_hz = 1000.0;
+  const double min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+  return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+static double mel_to_hz(double m) {
+  const double f_sp = 200.0 / 3, min_log_hz = 1000.0;
+  const double min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+  return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+static void build_mel_dense(const afx_params& p, std::vector<float>& W) {
+  const int M = p.n_mels, NB = p.n_fft / 2 + 1;
+  const double fmax = (double)p.sr / 2.0;
+  // mel_frequencies(n_mels + 2): np.linspace in the mel domain
+  std::vector<double> mel_f(M + 2);
+  const double m0 = hz_to_mel(0.0), m1 = hz_to_mel(fmax);
+  const double step = (m1 - m0) / (double)(M + 1);
+  for (int i = 0; i < M + 2; ++i) mel_f[i] = mel_to_hz(i == M + 1 ? m1 : (double)i * step + m0);
+  W.assign((size_t)M * NB, 0.f);
+  for (int i = 0; i < M; ++i) {
+    const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+    const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+    for (int k = 0; k < NB; ++k) {
+      // np.fft.rfftfreq(n, d=1/sr): arange(N) * (1.0 / (n * d))
+      const double fk = (double)k * (1.0 / ((double)p.n_fft * (1.0 / (double)p.sr)));
+      const double lower = -(mel_f[i] - fk) / fd0;
+      const double upper = (mel_f[i + 2] - fk) / fd1;
+      const double tri = std::fmax(0.0, std::fmin(lower, upper));
+      const float w32 = (float)tri;                 // weights[i] = ... (float32 array)
+      W[(size_t)i * NB + k] = (float)((double)w32 * enorm);   // weights *= enorm[:, None]
+    }
+  }
+}
+
+static void build_mel_sparse(const afx_params& p, const std::vector<float>& W, MelSparse& s) {
+  const int M = p.n_mels, NB = p.n_fft / 2 + 1;
+  s.k0.assign(M, 0); s.ntap4.assign(M, 0); s.woff.assign(M, 0); s.taps.clear();
+  for (int m = 0; m < M; ++m) {
+    int first = -1, last = -1;
+    for (int k = 0; k < NB; ++k)
+      if (W[(size_t)m * NB + k] != 0.f) { if (first < 0) first = k; last = k; }
+    s.woff[m] = (int32_t)s.taps.size();
+    if (first < 0) continue;                        // empty filter: mel = 0
+    const int nnz = last - first + 1;
+    const int n4 = (nnz + 3) / 4;
+    s.k0[m] = first; s.ntap4[m] = n4;
+    for (int i = 0; i < n4 * 4; ++i)
+      s.taps.push_back(i < nnz ? W[(size_t)m * NB + first + i] : 0.f);
+  }
+  if (s.taps.empty()) s.taps.push_back(0.f);
+}
+
+void build_host_tables(const afx_params& p, HostTables& t) {
+  const int N = p.n_fft, N2 = N / 2, M = p.n_mels, K = p.n_mfcc;
+  t.window.resize(N);
+  for (int n = 0; n < N; ++n) {
+    const double c = std::cos(2.0 * kPi * (double)n / (double)N);
+    t.window[n] = (float)(p.window == AFX_WINDOW_HANN ? 0.5 - 0.5 * c : 0.54 - 0.46 * c);
+  }
+  build_mel_dense(p, t.mel_dense);
+  build_mel_sparse(p, t.mel_dense, t.mel);
+  t.dct.resize((size_t)K * M);
+  for (int k = 0; k < K; ++k) {
+    const double s = k == 0 ? std::sqrt(1.0 / M) : std::sqrt(2.0 / M);
+    for (int m = 0; m < M; ++m)
+      t.dct[(size_t)k * M + m] = (float)(s * std::cos(kPi * k * (2.0 * m + 1.0) / (2.0 * M)));
+  }
+  t.tw.resize((size_t)2 * N2); t.post.resize((size_t)2 * N2);
+  for (int n = 0; n < N2; ++n) {
+    const double a = -2.0 * kPi * (double)n / (double)N2;
+    t.tw[2 * n] = (float)std::cos(a); t.tw[2 * n + 1] = (float)std::sin(a);
+    const double b = -2.0 * kPi * (double)n / (double)N;
+    t.post[2 * n] = (float)std::cos(b); t.post[2 * n + 1] = (float)std::sin(b);
+  }
+}
+
+}  // namespace afx
+
+extern "C" void afx_default_params(afx_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->sr = 22050; p->n_fft = 1024; p->hop = 256; p->n_mfcc = 13; p->n_mels = 128;
+  p->window = AFX_WINDOW_HAMMING; p->preemph = 0.97f; p->trim_top_db = 30.f;
+  p->trim_frame = 2048; p->trim_hop = 512; p->top_db = 80.f; p->amin = 1e-10f;
+  p->delta_width = 9;
+}
+
+extern "C" int afx_build_tables(const afx_params* p, float* window, float* mel_dense, float* dct) {
+  if (!p) { afx::set_error("afx_build_tables: null params"); return AFX_ERR_INVALID; }
+  std::string msg;
+  int st = afx::validate_params(*p, msg);
+  if (st != AFX_OK) { afx::set_error(msg); return st; }
+  afx::HostTables t;
+  afx::build_host_tables(*p, t);
+  if (window) std::memcpy(window, t.window.data(), t.window.size() * sizeof(float));
+  if (mel_dense) std::memcpy(mel_dense, t.mel_dense.data(), t.mel_dense.size() * sizeof(float));
+  if (dct) std::memcpy(dct, t.dct.data(), t.dct.size() * sizeof(float));
+  return AFX_OK;
+}

@@ -1,0 +1,161 @@
+"""Embarrassingly parallel file sharding for ``batch_process``.
+
+Clips are independent (every cross-frame coupling -- trim max, top_db max, delta
+stencil, mean/std -- is intra-clip), so N GPUs = N independent shards and the only
+"collective" is a host-side gather of 4*n_mfcc+3 floats per file.  No RCCL, no xGMI
+traffic.  Two deployment shapes share the partition/gather helpers here:
+
+* in-process: one worker thread per visible GPU, each with its own afx context,
+  plan and stream (``process_files``; what ``AudioFeatureExtractor.batch_process`` uses);
+* one process per GPU under ``torch.distributed`` (``shard_range`` + ``gather_shards``;
+  what ``bench.py --gpus N`` uses) -- the reference's only parallel precedent is a
+  ``multiprocessing.Pool`` over files
+  (04_feature_extraction_experiment/feature_extraction_for_student.py:168-174).
+"""
+from __future__ import annotations
+
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from typing import Any, Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from . import _native, wavio
+
+
+def lpt_partition(lengths: Sequence[int], n_parts: int) -> List[List[int]]:
+    """Longest-processing-time-first: sort by length (desc), give each clip to the least
+    loaded part.  Equal lengths degenerate to a round-robin deal.  Every part keeps its
+    indices in ascending order."""
+    n_parts = max(1, int(n_parts))
+    parts: List[List[int]] = [[] for _ in range(n_parts)]
+    load = [0] * n_parts
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    for i in order:
+        p = min(range(n_parts), key=lambda q: (load[q], q))
+        parts[p].append(i)
+        load[p] += int(lengths[i]) + 1
+    for p in parts:
+        p.sort()
+    return parts
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous balanced shard [lo, hi) of rank ``rank`` out of ``world``."""
+    base, rem = divmod(int(n_items), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_shards(local: np.ndarray, n_total: int, rank: int, world: int, group=None) -> np.ndarray:
+    """All ranks contribute the rows of their ``shard_range`` shard; every rank gets the
+    [n_total, ...] array in global order.  Host-side gather (gloo or nccl-backed object
+    gather); the data path itself has no collective."""
+    if world == 1:
+        return np.asarray(local)
+    import torch.distributed as dist
+    parts: List[Any] = [None] * world
+    dist.all_gather_object(parts, np.asarray(local), group=group)
+    out = np.concatenate([np.asarray(p) for p in parts], axis=0)
+    if out.shape[0] != n_total:
+        raise RuntimeError(f"gathered {out.shape[0]} rows, expected {n_total}")
+    return out
+
+
+def _decode(path: str, sr: int):
+    """-> ('s16'|'f32', mono array) ; PCM16 mono files at the target rate stay int16 so that
+    the upload is 2 bytes/sample and the /32768 happens on the GPU (bit-identical)."""
+    a, rate, kind = wavio.read_wav_raw(path)
+    if kind == "s16" and a.shape[1] == 1 and rate == sr:
+        return "s16", np.ascontiguousarray(a[:, 0])
+    y = wavio.to_mono(wavio.to_float32(a, kind))
+    if rate != sr:
+        y = wavio.resample(y, rate, sr)
+    return "f32", y
+
+
+def _pack(clips: List[np.ndarray], dtype) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Packs clips with 4-element alignment (enables the kernels' 16-byte loads)."""
+    lengths = np.array([c.size for c in clips], np.int64)
+    padded = (lengths + 3) // 4 * 4
+    offsets = np.zeros(len(clips), np.int64)
+    if len(clips):
+        offsets[1:] = np.cumsum(padded)[:-1]
+    buf = np.zeros(int(padded.sum()), dtype)
+    for c, o in zip(clips, offsets):
+        buf[o:o + c.size] = c
+    return buf, offsets, lengths
+
+
+def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 1024 * 1024) -> List[Dict[str, Any]]:
+    """Decode -> shard over GPUs -> fused extract -> dicts in input (glob) order."""
+    log = extractor.logger
+    n = len(files)
+    if n == 0:
+        return []
+    devices = extractor._devices()
+    decoded: List[Any] = [None] * n
+    errors: List[Any] = [None] * n
+
+    def dec(i):
+        try:
+            decoded[i] = _decode(str(files[i]), extractor.sr)
+        except Exception as e:          # load_audio: log + the file is dropped
+            log.error(f"載入音頻文件失敗: {str(e)}")
+            errors[i] = e
+
+    with ThreadPoolExecutor(max(1, min(16, n))) as ex:
+        list(ex.map(dec, range(n)))
+
+    ok = [i for i in range(n) if decoded[i] is not None]
+    K = extractor.n_mfcc
+    stats = np.zeros((n, 4 * K + 3), np.float32)
+    status = np.full(n, -1, np.int32)
+    nframes = np.zeros(n, np.int32)
+    parts = lpt_partition([decoded[i][1].size for i in ok], len(devices))
+    flags = _native.FLAG_PREEMPH | _native.FLAG_TRIM
+
+    def worker(dev, idxs):
+        try:
+            plan = extractor._plan(dev)
+            for kind, fmt, dt in (("s16", _native.FMT_S16, np.int16), ("f32", _native.FMT_F32, np.float32)):
+                sel = [ok[j] for j in idxs if decoded[ok[j]][0] == kind]
+                pos = 0
+                while pos < len(sel):
+                    tot, end = 0, pos
+                    while end < len(sel) and (end == pos or tot + decoded[sel[end]][1].size <= max_batch_samples):
+                        tot += decoded[sel[end]][1].size
+                        end += 1
+                    chunk = sel[pos:end]
+                    buf, offs, lens = _pack([decoded[i][1] for i in chunk], dt)
+                    out = plan.extract_batch(buf, offs, lens, flags=flags, fmt=fmt)
+                    stats[chunk] = out["stats"]
+                    status[chunk] = out["status"]
+                    nframes[chunk] = out["nframes"]
+                    pos = end
+        except Exception as e:          # a device-level failure drops that shard's files
+            for j in idxs:
+                if errors[ok[j]] is None and status[ok[j]] < 0:
+                    errors[ok[j]] = e
+
+    threads = [threading.Thread(target=worker, args=(d, p)) for d, p in zip(devices, parts) if p]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+
+    results: List[Dict[str, Any]] = []
+    from .core.feature_extractor import _status_error
+    for i, f in enumerate(files):
+        name = getattr(f, "name", str(f))
+        err = errors[i]
+        if err is None and status[i] != _native.CLIP_OK:
+            err = _status_error(int(status[i]), "extract_features", int(nframes[i]))
+            log.error(f"特徵提取失敗: {str(err)}")
+        if err is not None:
+            log.error(f"處理文件 {name} 失敗: {str(err)}")
+            continue
+        mfcc, energy = extractor._stats_to_dicts(stats[i])
+        results.append({"file_path": str(f), **extractor.extract_f0(None), **mfcc, **energy})
+        log.info(f"成功處理文件: {name}")
+    return results

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- MFCC frames/sec of the fused HIP hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]; configs[3] when N > 1): per GPU, 1000 synthetic
+10 s clips @22050 Hz, frame_length=1024, hop_length=256, n_mfcc=13 (SURVEY.md 8(d)
+generator), already resident in HBM when the timed region starts.  One "step" = one
+pass of preprocess_audio -> extract_mfcc + extract_energy over that batch
+(trim, fused frame kernel, DCT, statistics; 4*13+3 floats per clip copied back).
+Scaling is weak: every rank owns its own 1000 clips, no data-path collective; the only
+torch.distributed traffic is the timing barrier and the max-over-ranks reduction.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     -- k_frames (dominant kernel): algorithmic bytes = 4*hop per frame (each
+                  input sample read once) / average launch duration from HIP events
+                  recorded on the kernel's own stream inside the timed region;
+  cpu_baseline -- the numpy/scipy oracle (a port of the reference's librosa path) timed
+                  on this box's host cores over a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SR, SECONDS, N_FFT, HOP, N_MFCC = 22050, 10.0, 1024, 256, 13
+CLIPS_PER_GPU = 1000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def _cpu_clip_job(idx: int) -> int:
+    """One clip through the oracle, single-threaded (worker of the all-core pool too)."""
+    import numpy as np  # noqa: F401
+    from audio_feature_extraction_amd.synth import make_clip
+    from oracle import cpu_ref
+    y = make_clip(idx, SR, SECONDS)
+    out = cpu_ref.extract_stats(y, sr=SR, frame_length=N_FFT, hop_length=HOP, n_mfcc=N_MFCC)
+    return 1 + (out["trim"][1] - out["trim"][0]) // HOP
+
+
+def cpu_baseline(n_single: int, n_pool: int) -> dict:
+    """Times the CPU oracle: one core (BLAS pinned to 1 thread), then a spawn-pool over
+    cpu_count-1 workers (the reference's only parallel harness is a Pool over files)."""
+    import numpy as np
+    from audio_feature_extraction_amd.synth import make_clip
+    from oracle import cpu_ref
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    clips = [make_clip(i, SR, SECONDS) for i in range(n_single)]
+    frames = 0
+
+    def run():
+        nonlocal frames
+        frames = 0
+        for y in clips:
+            out = cpu_ref.extract_stats(y, sr=SR, frame_length=N_FFT, hop_length=HOP, n_mfcc=N_MFCC)
+            frames += 1 + (out["trim"][1] - out["trim"][0]) // HOP
+
+    cpu_ref.extract_stats(clips[0], sr=SR, frame_length=N_FFT, hop_length=HOP, n_mfcc=N_MFCC)  # warm
+    t0 = time.perf_counter()
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            run()
+    else:
+        run()
+    dt = time.perf_counter() - t0
+    res = {
+        "value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": f"{n_single} of the {CLIPS_PER_GPU} clips (10 s @22050 Hz, 1024/256/13), "
+                  f"numpy/scipy oracle, single thread, {dt:.1f} s",
+        "host_cpus": os.cpu_count(),
+    }
+    ncpu = os.cpu_count() or 1
+    if n_pool > 0 and ncpu > 2:
+        import multiprocessing as mp
+        workers = max(1, min(ncpu - 1, 32))
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
+        os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+        with mp.get_context("spawn").Pool(workers) as pool:
+            pool.map(_cpu_clip_job, range(workers))           # warm the workers (imports)
+            t0 = time.perf_counter()
+            fr = sum(pool.map(_cpu_clip_job, range(n_pool), chunksize=1))
+            dt2 = time.perf_counter() - t0
+        res["all_cores"] = {"value": fr / dt2, "unit": "frames/s", "cores": workers,
+                            "sample": f"{n_pool} clips over a {workers}-process pool, {dt2:.1f} s"}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    res["cpu_model"] = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return res
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU (default: the BASELINE config)")
+    ap.add_argument("--cpu-clips", type=int, default=24, help="clips timed on one CPU core (0 = skip the CPU baseline)")
+    ap.add_argument("--cpu-pool-clips", type=int, default=96)
+    ap.add_argument("--no-timing-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    distributed = world > 1
+
+    # CPU baseline first (rank 0, N=1 only), before this process touches the GPU
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_clips > 0:
+        cpu = cpu_baseline(args.cpu_clips, args.cpu_pool_clips)
+
+    import numpy as np
+    import torch
+    from audio_feature_extraction_amd import _native as N
+    from audio_feature_extraction_amd.synth import make_batch
+
+    if not torch.cuda.is_available() or N.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    n_clips = args.clips
+    workers = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    samples, offsets, lengths = make_batch(n_clips, SR, SECONDS, first_index=rank * n_clips, workers=workers)
+
+    ctx = N.Context(local_rank)
+    plan = N.Plan(ctx, N.make_params(SR, N_FFT, HOP, N_MFCC))
+    dbuf = N.DeviceBuffer(ctx, samples.nbytes)
+    dbuf.upload(samples)
+    out = None
+
+    def step():
+        nonlocal out
+        out = plan.extract_batch(dbuf, offsets, lengths, out=out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if out is None:
+        step()
+    assert int((out["status"] != 0).sum()) == 0, "synthetic clips must all succeed"
+    frames_per_step = int(out["nframes"].sum())
+
+    # PCIe-inclusive rate (host float32 -> stats), reported beside the HBM-resident value
+    h0 = time.perf_counter()
+    plan.extract_batch(samples, offsets, lengths)
+    host_dt = time.perf_counter() - h0
+
+    if not args.no_timing_events:
+        plan.set_timing(True)
+        plan.timings(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kt = plan.timings() if not args.no_timing_events else None
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_frames = frames_per_step * world * args.steps
+        value = total_frames / elapsed
+        roof = None
+        if kt is not None and kt["frames"][1] > 0:
+            avg_ms = kt["frames"][0] / kt["frames"][1]
+            achieved = frames_per_step * 4.0 * HOP / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_frames<1024>",
+                    "avg_launch_ms": avg_ms,
+                    "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in kt.items()}}
+        line = {
+            "metric": "audio frames/sec (sr=22050, n_fft=1024, hop=256, n_mfcc=13)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n_clips}x10s clips @22050 Hz per GPU, frame_length=1024, hop_length=256, "
+                                   f"n_mfcc=13, n_mels=128, hamming, pre-emphasis 0.97 + trim 30 dB + RMS "
+                                   f"(BASELINE configs[{1 if world == 1 else 3}])",
+                       "clips_per_gpu": n_clips, "frames_per_gpu_step": frames_per_step,
+                       "parallelism": f"file-shard x{world}, no collective", "input": "HBM-resident float32"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "host_to_result_frames_per_s": frames_per_step / host_dt,
+        }
+        print(json.dumps(line), flush=True)
+
+    dbuf.free()
+    plan.close()
+    ctx.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

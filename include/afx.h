@@ -1,0 +1,165 @@
+/*
+ * afx.h -- C ABI of libafx.so, the MI355X (gfx950) MFCC / RMS engine.
+ *
+ * The reference (chiy48308/audio_feature_extraction) has no FFI: its hot path is
+ * three Python methods that call librosa.  This header is the seam a maintainer
+ * binds with ctypes; each entry point names the reference
+ * call(s) it replaces.  Paths are relative to the reference root,
+ *   F = audio_feature_extraction_toolkit/core/feature_extractor.py
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes, no torch / HIP types in signatures;
+ *   - every function returns 0 (AFX_OK) or a negative afx_status; nothing throws
+ *     across the ABI; afx_last_error() gives the text of the last failure on the
+ *     calling thread;
+ *   - the caller owns every buffer it passes; the library never frees them;
+ *   - an afx_ctx is bound to one HIP device and owns one stream; it is not
+ *     thread-safe -- use one ctx per worker thread (one per GPU);
+ *   - all entry points are synchronous on return;
+ *   - a per-clip failure is reported in out_status[] and never fails the batch
+ *     (maps onto batch_process's per-file try/except, F:229-235).
+ */
+#ifndef AFX_H
+#define AFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFX_VERSION 100
+
+typedef enum afx_status {
+  AFX_OK = 0,
+  AFX_ERR_INVALID = -1,     /* bad argument / unsupported parameter combination */
+  AFX_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+  AFX_ERR_HIP = -3,         /* a HIP runtime call or kernel launch failed */
+  AFX_ERR_NOMEM = -4,
+  AFX_ERR_UNSUPPORTED = -5  /* e.g. n_fft not a power of two in [256, 4096] */
+} afx_status;
+
+/* per-clip status written to out_status[] */
+typedef enum afx_clip_status {
+  AFX_CLIP_OK = 0,
+  AFX_CLIP_TOO_SHORT = 1,  /* fewer than delta_width frames, or < 2 samples:
+                              librosa.feature.delta raises ParameterError (F:137) */
+  AFX_CLIP_NONFINITE = 2   /* NaN/Inf sample: librosa.util.valid_audio raises */
+} afx_clip_status;
+
+enum { AFX_WINDOW_HAMMING = 0, AFX_WINDOW_HANN = 1 };
+enum { AFX_FMT_F32 = 0, AFX_FMT_S16 = 1 };           /* S16: value / 32768 (libsndfile) */
+enum { AFX_MEM_HOST = 0, AFX_MEM_DEVICE = 1 };
+
+/* flags for afx_extract_batch */
+enum {
+  AFX_FLAG_PREEMPH = 1,    /* apply pre-emphasis (F:69); off for extract_mfcc(y)/extract_energy(y) */
+  AFX_FLAG_TRIM = 2        /* apply silence trim (F:72) */
+};
+
+/* Constructor arguments of AudioFeatureExtractor (F:10-17) plus the values the
+ * reference hard-codes at its librosa call sites. */
+typedef struct afx_params {
+  int32_t sr;            /* F:11  */
+  int32_t n_fft;         /* frame_length, F:12 -> n_fft of librosa.feature.mfcc (F:131) */
+  int32_t hop;           /* F:13  */
+  int32_t n_mfcc;        /* F:14  */
+  int32_t n_mels;        /* librosa default 128 (the reference never passes it) */
+  int32_t window;        /* AFX_WINDOW_HAMMING: F:133 */
+  float   preemph;       /* F:17, 0.97 */
+  float   trim_top_db;   /* 30, F:72 */
+  int32_t trim_frame;    /* 2048, librosa.effects.trim default */
+  int32_t trim_hop;      /* 512 */
+  float   top_db;        /* 80, librosa.power_to_db default */
+  float   amin;          /* 1e-10 */
+  int32_t delta_width;   /* 9, librosa.feature.delta default */
+  int32_t reserved;
+} afx_params;
+
+typedef struct afx_ctx afx_ctx;
+typedef struct afx_plan afx_plan;
+
+/* ---- library / device ---------------------------------------------------- */
+int afx_version(void);
+int afx_device_count(void);                       /* 0 when no GPU is visible */
+const char* afx_last_error(void);                 /* thread-local, never NULL */
+
+int afx_init(int device, afx_ctx** out);          /* binds device, creates the stream */
+void afx_destroy(afx_ctx* ctx);
+
+/* device memory helpers so that a binding needs no HIP API of its own */
+int afx_malloc(afx_ctx* ctx, size_t bytes, void** out_dptr);
+int afx_free(afx_ctx* ctx, void* dptr);
+int afx_memcpy_h2d(afx_ctx* ctx, void* dst_d, const void* src_h, size_t bytes);
+int afx_memcpy_d2h(afx_ctx* ctx, void* dst_h, const void* src_d, size_t bytes);
+int afx_synchronize(afx_ctx* ctx);
+
+/* ---- plan: window / twiddle / sparse-mel / DCT tables for one parameter set  */
+void afx_default_params(afx_params* p);           /* reference defaults (F:10-17, F:72, F:133) */
+int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out);
+void afx_plan_destroy(afx_plan* plan);
+
+/* Host-only table builders (no device needed) -- what afx_plan_create uploads.
+ * window[n_fft]; mel_dense[n_mels * (n_fft/2+1)] row-major (librosa.filters.mel
+ * float32 values); dct[n_mfcc * n_mels] (ortho DCT-II rows).  Any pointer may be
+ * NULL.  Replaces scipy.signal.get_window / librosa.filters.mel / scipy.fft.dct
+ * table construction under librosa.feature.mfcc (F:127). */
+int afx_build_tables(const afx_params* p, float* window, float* mel_dense, float* dct);
+
+/* ---- the hot path ---------------------------------------------------------
+ * One pass of preprocess_audio -> extract_mfcc + extract_energy (F:194,198,199)
+ * over a ragged batch of clips.
+ *
+ *   samples   packed clips (AFX_FMT_F32 float or AFX_FMT_S16 int16_t), in host
+ *             or device memory (mem_kind); clip i is
+ *             samples[offsets[i] .. offsets[i]+lengths[i])  (element units)
+ *   offsets, lengths   host arrays, n_clips entries
+ *   flags     AFX_FLAG_PREEMPH | AFX_FLAG_TRIM for extract_features semantics
+ *   out_stats host, n_clips * (4*n_mfcc + 3) floats per clip:
+ *             mfcc_mean[K] mfcc_std[K] mfcc_delta_mean[K] mfcc_delta2_mean[K]
+ *             energy_mean energy_std energy_range        (F:141-150, F:171-178)
+ *   out_status host int32[n_clips]  (afx_clip_status)
+ *   out_trim  host int64[2*n_clips] (start, end) of the kept span, or NULL
+ *   out_nframes host int32[n_clips] T = 1 + (end-start)/hop, or NULL
+ *   out_frames  NULL, or host float buffer for the per-frame matrices the
+ *             reference computes and then reduces (F:127-138, F:164): clip i
+ *             occupies rows of stride Tmax_i = 1 + lengths[i]/hop starting at
+ *             float index frame_offsets[i]: (3*n_mfcc + 1) rows
+ *             [mfcc K | delta K | delta2 K | rms 1], first T_i entries valid.
+ *   frame_offsets host int64[n_clips] (ignored when out_frames is NULL)
+ */
+int afx_extract_batch(afx_plan* plan,
+                      const void* samples, int sample_fmt, int mem_kind,
+                      const int64_t* offsets, const int64_t* lengths, int n_clips,
+                      int flags,
+                      float* out_stats, int32_t* out_status,
+                      int64_t* out_trim, int32_t* out_nframes,
+                      float* out_frames, const int64_t* frame_offsets);
+
+/* preprocess_audio(y) (F:58-74): pre-emphasis + trim of ONE host clip.
+ * out_y receives the n pre-emphasised samples (host, n floats); the kept span
+ * is out_y[*start .. *end). */
+int afx_preprocess(afx_plan* plan, const float* y, int64_t n,
+                   float* out_y, int64_t* start, int64_t* end, int32_t* status);
+
+/* ---- measurement ---------------------------------------------------------
+ * When enabled, afx_extract_batch brackets every kernel with HIP events on the
+ * plan's stream.  afx_plan_get_timings returns, per kernel slot, the summed
+ * milliseconds and launch count since the last reset. */
+enum {
+  AFX_K_TRIM_BLOCKS = 0,   /* per-512-sample block sums of squares of y_pre */
+  AFX_K_TRIM_DECIDE = 1,   /* per-clip max / threshold scan -> [start,end), T */
+  AFX_K_FRAMES = 2,        /* fused framing+window+rFFT+power+mel+dB (+RMS)  -- dominant */
+  AFX_K_DCT = 3,           /* top_db clamp + DCT-II */
+  AFX_K_STATS = 4,         /* delta/delta2 + per-clip statistics */
+  AFX_K_COUNT = 5
+};
+int afx_plan_set_timing(afx_plan* plan, int enable);
+int afx_plan_get_timings(afx_plan* plan, float* ms_sum /*[AFX_K_COUNT]*/,
+                         int32_t* launches /*[AFX_K_COUNT]*/, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFX_H */
