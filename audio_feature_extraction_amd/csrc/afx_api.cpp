@@ -3,6 +3,7 @@
 // See include/afx.h for the contract and the reference call sites replaced.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -166,8 +167,6 @@ static int upload(afx_plan* pl, const T* host, size_t count, const T** dev) {
   return AFX_OK;
 }
 
-static int kmax_bucket(int K) { return K <= 16 ? 16 : K <= 32 ? 32 : K <= 64 ? 64 : 128; }
-
 extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out) {
   if (!ctx || !p || !out) { set_error("afx_plan_create: null argument"); return AFX_ERR_INVALID; }
   *out = nullptr;
@@ -179,7 +178,7 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
   afx_plan* pl = new afx_plan();
   pl->ctx = ctx; pl->p = *p;
   build_host_tables(*p, pl->ht);
-  const size_t lds = frames_lds_bytes(p->n_fft, p->hop, (int)pl->ht.mel.taps.size(), p->n_mels);
+  const size_t lds = frames_lds_bytes(p->n_fft, p->hop);
   if (lds == 0 || lds > 160 * 1024) {
     delete pl;
     set_error("frame_length/hop_length combination needs more than 160 KiB of LDS per workgroup (hop too large)");
@@ -193,20 +192,23 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
   kp.flags = 0; kp.fmt = AFX_FMT_F32;
   int rc = AFX_OK;
   const HostTables& t = pl->ht;
-  std::vector<float> dct_pad((size_t)kmax_bucket(p->n_mfcc) * p->n_mels, 0.f);
-  std::memcpy(dct_pad.data(), t.dct.data(), t.dct.size() * sizeof(float));
+  const int4* grp4 = nullptr;
+  const float4* coef4 = nullptr;
   if ((rc = upload(pl, t.window.data(), t.window.size(), &pl->dt.window)) != AFX_OK ||
       (rc = upload(pl, t.tw.data(), t.tw.size(), &pl->dt.tw)) != AFX_OK ||
       (rc = upload(pl, t.post.data(), t.post.size(), &pl->dt.post)) != AFX_OK ||
-      (rc = upload(pl, t.mel.taps.data(), t.mel.taps.size(), &pl->dt.taps)) != AFX_OK ||
-      (rc = upload(pl, t.mel.k0.data(), t.mel.k0.size(), &pl->dt.mel_k0)) != AFX_OK ||
-      (rc = upload(pl, t.mel.ntap4.data(), t.mel.ntap4.size(), &pl->dt.mel_n4)) != AFX_OK ||
-      (rc = upload(pl, t.mel.woff.data(), t.mel.woff.size(), &pl->dt.mel_wo)) != AFX_OK ||
-      (rc = upload(pl, dct_pad.data(), dct_pad.size(), &pl->dt.dct)) != AFX_OK) {
+      (rc = upload(pl, reinterpret_cast<const float4*>(t.mel.coef.data()), t.mel.coef.size() / 4, &coef4)) != AFX_OK ||
+      (rc = upload(pl, t.mel.koff.data(), t.mel.koff.size(), &pl->dt.mel_koff)) != AFX_OK ||
+      (rc = upload(pl, reinterpret_cast<const int4*>(t.mel.grp.data()), t.mel.grp.size() / 4, &grp4)) != AFX_OK ||
+      (rc = upload(pl, t.mel.order.data(), t.mel.order.size(), &pl->dt.mel_order)) != AFX_OK ||
+      (rc = upload(pl, t.dctb.A.data(), t.dctb.A.size(), &pl->dt.dctA)) != AFX_OK) {
     afx_plan_destroy(pl);
     return rc;
   }
-  pl->dt.ntaps = (int32_t)t.mel.taps.size();
+  pl->dt.mel_grp = grp4;
+  pl->dt.mel_coef = coef4;
+  pl->dt.n_groups = t.mel.n_groups;
+  pl->dt.n_cgroups = t.dctb.n_cgroups;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
     pl->n_cu = prop.multiProcessorCount;
@@ -257,7 +259,7 @@ static int prepare_descriptors(afx_plan* pl, const int64_t* offsets, const int64
   pl->h_clips.resize(n);
   int64_t fb = 0, tb = 0;
   int max_tb = 0, max_tm = 0;
-  std::vector<int2> blocks;
+  int64_t nblk = 0;
   for (int i = 0; i < n; ++i) {
     if (lengths[i] < 0 || offsets[i] < 0) { set_error("negative clip offset/length"); return AFX_ERR_INVALID; }
     if (lengths[i] / hop > (int64_t)1 << 30) { set_error("clip too long"); return AFX_ERR_INVALID; }
@@ -271,18 +273,18 @@ static int prepare_descriptors(afx_plan* pl, const int64_t* offsets, const int64
     tb += ntb;
     max_tb = std::max<int>(max_tb, (int)ntb);
     max_tm = std::max<int>(max_tm, c.tmax);
-    for (int b = 0; b < c.tpad / kFramesPerBlock; ++b) blocks.push_back(make_int2(i, b));
+    c.blk_base = (int32_t)nblk; c.pad_ = 0;
+    nblk += c.tpad / kFramesPerBlock;
+    if (nblk > (int64_t)1 << 30) { set_error("batch too large"); return AFX_ERR_INVALID; }
   }
   pl->total_tpad = fb; pl->total_tblk = tb; pl->max_tblocks = std::max(max_tb, 1); pl->max_tmax = max_tm;
-  pl->nblocks = (int)blocks.size();
+  pl->nblocks = (int)nblk;
   int rc;
   if ((rc = ensure(pl->clips, n * sizeof(ClipDesc))) != AFX_OK) return rc;
-  if ((rc = ensure(pl->blocks, std::max<size_t>(blocks.size(), 1) * sizeof(int2))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->blocks, std::max<size_t>((size_t)nblk, 1) * sizeof(BlockDesc))) != AFX_OK) return rc;
   hipStream_t s = pl->ctx->stream;
   HIP_TRY(hipMemcpyAsync(pl->clips.p, pl->h_clips.data(), n * sizeof(ClipDesc), hipMemcpyHostToDevice, s));
-  if (!blocks.empty())
-    HIP_TRY(hipMemcpyAsync(pl->blocks.p, blocks.data(), blocks.size() * sizeof(int2), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));   // `blocks` is a local; descriptors change rarely
+  HIP_TRY(hipStreamSynchronize(s));   // h_clips may be rebuilt by the next call; descriptors change rarely
   pl->c_off.assign(offsets, offsets + n);
   pl->c_len.assign(lengths, lengths + n);
   return AFX_OK;
@@ -334,15 +336,16 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
 
   KParams kp = pl->kp;
   kp.flags = flags; kp.fmt = fmt;
+  if (const char* dbg = getenv("AFX_DEBUG_SKIP")) kp.flags |= (atoi(dbg) & 7) << 8;   // timing ablation only
   const ClipDesc* d_clips = (const ClipDesc*)pl->clips.p;
   ClipInfo* d_info = (ClipInfo*)pl->info.p;
 
   HIP_TRY(hipMemsetAsync(d_info, 0, n * sizeof(ClipInfo), s));
   TIMED(AFX_K_TRIM_BLOCKS, launch_trim_blocks(s, d_samples, d_clips, d_info, (float*)pl->bsum.p, n, pl->max_tblocks, kp));
-  TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, n, kp));
+  TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, n, kp));
   if (pl->nblocks > 0) {
     const int grid = std::min(pl->nblocks, pl->n_cu * 2);
-    TIMED(AFX_K_FRAMES, launch_frames(s, d_samples, d_clips, d_info, (const int2*)pl->blocks.p, pl->nblocks,
+    TIMED(AFX_K_FRAMES, launch_frames(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks,
                                       pl->dt, kp, (float*)pl->logmel.p, (float*)pl->rms.p, grid));
     TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax));
   }
@@ -418,7 +421,7 @@ extern "C" int afx_preprocess(afx_plan* pl, const float* y, int64_t n, float* ou
   ClipInfo* d_info = (ClipInfo*)pl->info.p;
   HIP_TRY(hipMemsetAsync(d_info, 0, sizeof(ClipInfo), s));
   HIP_TRY(launch_trim_blocks(s, pl->samples.p, (const ClipDesc*)pl->clips.p, d_info, (float*)pl->bsum.p, 1, pl->max_tblocks, kp));
-  HIP_TRY(launch_trim_decide(s, (const ClipDesc*)pl->clips.p, d_info, (const float*)pl->bsum.p, 1, kp));
+  HIP_TRY(launch_trim_decide(s, (const ClipDesc*)pl->clips.p, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, 1, kp));
   if (n > 0) {
     HIP_TRY(launch_preemph(s, (const float*)pl->samples.p, (float*)pl->logmel.p, n, kp.preemph_b1));
     HIP_TRY(hipMemcpyAsync(out_y, pl->logmel.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));

@@ -19,7 +19,23 @@ struct ClipDesc {
   int64_t tblk_base;   // first trim-block slot of this clip
   int32_t tmax;        // 1 + N / hop   (frame count before trim)
   int32_t tpad;        // tmax rounded up to a multiple of 16
+  int32_t blk_base;    // first k_frames block (16 frames) of this clip
+  int32_t pad_;
 };
+
+// One per 16-frame block of k_frames, written by k_trim_decide once the kept span is known,
+// so that k_frames needs a single 64-byte fetch per block (no dependent clip lookups).
+// Staged index j (0 .. 15*hop + n_fft) is sample g0 + j of the clip, g0 = start + t0*hop - n_fft/2.
+struct BlockDesc {
+  int64_t sample_base;   // element index of staged sample 0 in the packed buffer (clip off + g0)
+  int64_t frame_slot;    // clip frame_base + t0
+  int64_t clip_off;      // element index of the clip's sample 0
+  int32_t keep_lo, keep_hi;   // j kept by trim iff keep_lo <= j < keep_hi (else staged as zero)
+  int32_t have_lo, have_hi;   // sample exists iff have_lo <= j < have_hi   (have_lo = -g0)
+  int32_t clip, t0, T, active;
+  int32_t pad_[2];
+};
+static_assert(sizeof(BlockDesc) == 64, "BlockDesc must be 64 bytes");
 
 // Device-written, per clip (k_trim_decide), read by every later kernel.
 struct ClipInfo {
@@ -34,12 +50,13 @@ struct DevTables {
   const float* window;   // n_fft
   const float* tw;       // n_fft/2 complex
   const float* post;     // n_fft/2 complex
-  const float* taps;     // padded sparse mel taps
-  const int32_t* mel_k0;
-  const int32_t* mel_n4;
-  const int32_t* mel_wo;
-  const float* dct;      // n_mfcc x n_mels
-  int32_t ntaps;         // floats in taps
+  const float4* mel_coef; // per (group, row): a_lo, b_lo, a_hi, b_hi of the filter's triangle
+  const float* mel_koff;  // per (group, row): kmin - kc
+  const int4* mel_grp;   // per 16-filter group: kmin, nblk, first block, group id
+  const int32_t* mel_order;
+  const float* dctA;     // DCT-II rows as MFMA A images
+  int32_t n_groups;      // ceil(n_mels / 16)
+  int32_t n_cgroups;     // ceil(n_mfcc / 16)
 };
 
 struct KParams {
@@ -51,15 +68,15 @@ struct KParams {
   int32_t fmt;           // AFX_FMT_*
 };
 
-// dynamic LDS bytes k_frames needs for (n_fft, hop, ntaps, n_mels); 0 if n_fft unsupported
-size_t frames_lds_bytes(int n_fft, int hop, int ntaps, int n_mels);
+// dynamic LDS bytes k_frames needs for (n_fft, hop); 0 if n_fft unsupported
+size_t frames_lds_bytes(int n_fft, int hop);
 
 hipError_t launch_trim_blocks(hipStream_t s, const void* samples, const ClipDesc* clips, ClipInfo* info,
                               float* bsum, int n_clips, int max_tblocks, const KParams& kp);
 hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum,
-                              int n_clips, const KParams& kp);
-hipError_t launch_frames(hipStream_t s, const void* samples, const ClipDesc* clips, ClipInfo* info,
-                         const int2* blocks, int nblocks, const DevTables& tb, const KParams& kp,
+                              BlockDesc* blocks, int n_clips, const KParams& kp);
+hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
+                         const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
                          float* logmel, float* rms_rows, int grid);
 hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
                       const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax);

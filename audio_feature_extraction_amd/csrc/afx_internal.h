@@ -9,12 +9,26 @@
 
 namespace afx {
 
-// librosa.filters.mel rows stored sparsely: the non-zeros of filter m are the
-// contiguous bins [k0[m], k0[m]+nnz); taps are padded with zeros to a multiple
-// of 4 so that the four lane-quarters of a wave split a filter's taps evenly.
-struct MelSparse {
-  std::vector<int32_t> k0, ntap4, woff;   // per filter
-  std::vector<float> taps;                // sum(ntap4)*4 floats
+// librosa.filters.mel for v_mfma_f32_16x16x4_f32: filters are taken 16 at a time (a
+// "group"); a group touches the contiguous bin range [kmin, kmin + 4*nblk) and only
+// those 16x4 blocks are visited (136 of 1032 at 22050 Hz / 1024).  The A operand is not
+// tabulated: each lane evaluates its filter's triangle on the fly,
+//   w(k) = max(0, min(a_lo + b_lo*(k - kc), a_hi + b_hi*(k - kc)))      (Slaney norm folded in)
+// with the intercepts taken at the filter's peak bin kc, which keeps the float32 result
+// within ~3e-7 of the filter peak of librosa's float32 table (tests/test_native_cpu.py).
+struct MelBlocks {
+  int32_t n_groups = 0;
+  std::vector<int32_t> grp;     // 4 ints per group: kmin, nblk, first block, group id
+  std::vector<int32_t> order;   // processing order, dealt snake-wise over the 4 waves
+  std::vector<float> coef;      // per (group, row): a_lo, b_lo, a_hi, b_hi
+  std::vector<float> koff;      // per (group, row): kmin - kc  (k - kc = koff + 4*blk + q)
+};
+
+// ortho DCT-II rows as MFMA A-operand images: dctA[(c * (n_mels/4) + i) * 64 + l] =
+// D[16c + (l & 15)][4i + (l >> 4)], zero for coefficient rows >= n_mfcc.
+struct DctBlocks {
+  int32_t n_cgroups = 0;        // ceil(n_mfcc / 16)
+  std::vector<float> A;
 };
 
 struct HostTables {
@@ -23,7 +37,8 @@ struct HostTables {
   std::vector<float> dct;         // n_mfcc x n_mels, ortho DCT-II rows
   std::vector<float> tw;          // n_fft/2 complex: exp(-2*pi*i*n/(n_fft/2))
   std::vector<float> post;        // n_fft/2 complex: exp(-2*pi*i*k/n_fft)
-  MelSparse mel;
+  MelBlocks mel;
+  DctBlocks dctb;
 };
 
 // returns AFX_OK or a negative status; msg set on failure

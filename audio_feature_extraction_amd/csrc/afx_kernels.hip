@@ -13,7 +13,9 @@
 //   k_stats        F:137-150,171-178  Savitzky-Golay delta/delta2 (width 9, 'interp' edges) and the
 //                           per-clip mean / std / ptp reductions
 //
-// No MFMA: no stage is a dense contraction (butterflies, a 1.5 %-dense filterbank, a 13x128 DCT).
+// The FFT is VALU/LDS work.  The two contractions the reference runs densely (the mel einsum and the
+// DCT) go to the matrix pipe as exact-f32 v_mfma_f32_16x16x4_f32, the filterbank block-sparse (14 % of
+// its 16x4 blocks are non-zero), so they run beside the VALU instead of on it.
 #include <hip/hip_runtime.h>
 
 #include "afx_device.h"
@@ -54,21 +56,31 @@ __device__ __forceinline__ float preemph0(float y0, float y1) {
   return zi + y0;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+// Wave-wide reductions without LDS: DPP butterflies inside each 16-lane row, then one readlane per
+// row (__shfl_xor would lower to six dependent ds_bpermute round trips).
+#define AFX_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, false))
+template <typename Op>
+__device__ __forceinline__ float row_reduce(float v, Op op) {      // every lane ends with its row's total
+  v = op(v, AFX_DPP(v, 0xB1));     // quad_perm [1,0,3,2]
+  v = op(v, AFX_DPP(v, 0x4E));     // quad_perm [2,3,0,1]
+  v = op(v, AFX_DPP(v, 0x141));    // row_half_mirror
+  v = op(v, AFX_DPP(v, 0x140));    // row_mirror
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+template <typename Op>
+__device__ __forceinline__ float wave_reduce(float v, Op op) {     // uniform result
+  v = row_reduce(v, op);
+  const int vi = __float_as_int(v);          // readlane is an int builtin: bit-cast, do not convert
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+  return op(op(r0, r1), op(r2, r3));
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  return v;
-}
+struct OpAdd { __device__ float operator()(float a, float b) const { return a + b; } };
+struct OpMax { __device__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+struct OpMin { __device__ float operator()(float a, float b) const { return fminf(a, b); } };
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce(v, OpAdd()); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce(v, OpMax()); }
+__device__ __forceinline__ float wave_min(float v) { return wave_reduce(v, OpMin()); }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
@@ -144,7 +156,8 @@ __device__ __forceinline__ float trim_frame_rms(const float* bs, int64_t t, int6
 
 __global__ __launch_bounds__(256) void k_trim_decide(const ClipDesc* __restrict__ clips,
                                                      ClipInfo* __restrict__ info,
-                                                     const float* __restrict__ bsum, KParams kp) {
+                                                     const float* __restrict__ bsum,
+                                                     BlockDesc* __restrict__ blocks, KParams kp) {
   __shared__ float red_f[4];
   __shared__ long long red_a[4], red_b[4];
   const int clip = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -188,14 +201,28 @@ __global__ __launch_bounds__(256) void k_trim_decide(const ClipDesc* __restrict_
       end = (last + 1) * th < N ? (last + 1) * th : N;
     } else { start = 0; end = 0; }
   }
+  const int T = (int)(1 + (end - start) / kp.hop);
+  if (status == AFX_CLIP_OK && T < 9) status = AFX_CLIP_TOO_SHORT;   // librosa.feature.delta width 9
   if (tid == 0) {
-    const int64_t np = end - start;
-    const int T = (int)(1 + np / kp.hop);
-    if (status == AFX_CLIP_OK && T < 9) status = AFX_CLIP_TOO_SHORT;   // librosa.feature.delta width 9
     ClipInfo ci;
     ci.start = start; ci.end = end; ci.T = T; ci.status = status; ci.lmax_ord = 0u;
     ci.nonfinite = info[clip].nonfinite;
     info[clip] = ci;
+  }
+  // block descriptors of this clip for k_frames
+  const int64_t lim = (int64_t)1 << 30;
+  for (int fb = tid; fb < cd.tpad / kFramesPerBlock; fb += 256) {
+    BlockDesc d;
+    const int t0 = fb * kFramesPerBlock;
+    const int64_t g0 = start + (int64_t)t0 * kp.hop - kp.n_fft / 2;
+    auto rel = [&](int64_t x) { const int64_t r = x - g0; return (int32_t)(r < -lim ? -lim : (r > lim ? lim : r)); };
+    d.sample_base = cd.off + g0; d.frame_slot = cd.frame_base + t0; d.clip_off = cd.off;
+    d.keep_lo = rel(start); d.keep_hi = rel(end);
+    d.have_lo = rel(0); d.have_hi = rel(N);
+    d.clip = clip; d.t0 = t0; d.T = T;
+    d.active = (status == AFX_CLIP_OK && t0 < T) ? 1 : 0;
+    d.pad_[0] = 0; d.pad_[1] = 0;
+    blocks[cd.blk_base + fb] = d;
   }
 }
 
@@ -215,25 +242,31 @@ struct FC {
 
 __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 
-struct LdsLayout { int s, ex, pb, mw, mt, total; };   // float offsets
-__host__ __device__ inline LdsLayout lds_layout(int n_fft, int hop, int ntaps, int n_mels) {
+constexpr int kPbStride = 17;   // power-spectrum rows: 16 frames + 1 pad (conflict-free column writes)
+constexpr int kPbPadRows = 3;   // zero rows past the Nyquist bin: mel blocks are 4 bins wide
+
+// n_fft = 1024 (the headline configuration) runs a hand-scheduled 8x8x8 core: XOR-swizzled
+// exchange image without padding, window / split twiddles in LDS, two frames in flight per wave.
+__host__ __device__ inline bool fast1024(int n_fft) { return n_fft == 1024; }
+
+struct LdsLayout { int s, ex, pb, tab, total; };   // float offsets
+__host__ __device__ inline LdsLayout lds_layout(int n_fft, int hop) {
   const int N2 = n_fft / 2;
   const int lpf = (N2 / 8 >= 64) ? 64 : N2 / 8;
   const int fpw = 64 / lpf;
-  const int exn = N2 + (N2 >> 3);
+  const int exn = fast1024(n_fft) ? N2 : N2 + (N2 >> 3);
   LdsLayout L;
   L.s = 0;
   L.ex = L.s + round4((kFramesPerBlock - 1) * hop + n_fft);
   L.pb = L.ex + kWaves * fpw * exn * 2;
-  L.mw = L.pb + round4((N2 + 1) * 16);
-  L.mt = L.mw + round4(ntaps);
-  L.total = L.mt + round4(3 * n_mels);
+  L.tab = L.pb + round4((N2 + 1 + kPbPadRows) * kPbStride);
+  L.total = L.tab + (fast1024(n_fft) ? 4 * N2 : 0);      // window[N2] float2 + post[N2] float2
   return L;
 }
 
-size_t frames_lds_bytes(int n_fft, int hop, int ntaps, int n_mels) {
+size_t frames_lds_bytes(int n_fft, int hop) {
   if (n_fft != 256 && n_fft != 512 && n_fft != 1024 && n_fft != 2048) return 0;
-  return (size_t)lds_layout(n_fft, hop, ntaps, n_mels).total * sizeof(float);
+  return (size_t)lds_layout(n_fft, hop).total * sizeof(float);
 }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -325,47 +358,126 @@ template <> struct Sched<2048> { using C = FC<2048>; using P1 = Pass<C::N2, C::L
 template <typename PX> struct NTW { static constexpr int v = PX::NTW; };
 template <> struct NTW<void> { static constexpr int v = 0; };
 
-// power-spectrum buffer: bin-major, 16 frames per row, frame index XOR-swizzled
-// by the bin so that both the per-frame column writes (32 consecutive bins) and
-// the per-bin row reads (16 frames, two bins of opposite parity per 32 lanes)
-// are bank-conflict-free with ds_*_b32.
-__device__ __forceinline__ int pbidx(int k, int f) { return k * 16 + (f ^ ((k >> 1) & 15)); }
+// raw samples of one staged quad (4 consecutive samples + the one before them)
+struct RawQuad { float y0, y1, y2, y3, prev; };
+
+struct BlkCtx {          // uniform per workgroup; one BlockDesc resolved into scalars
+  int64_t sample_base, frame_slot, clip_off;
+  int keep_lo, keep_hi, have_lo, have_hi;
+  int clip, t0, T;
+  bool active, interior;
+};
+
+// staged index j -> raw samples j-1 .. j+3 of the block (zeros outside the clip).
+// Branch-free on purpose: a per-lane "load or keep" branch makes hipcc wait vmcnt(0) inside every
+// branch, which serialises the prefetch.  `interior` is uniform per block: every staged sample and
+// its predecessor exist and the quads are 16-byte (F32) / 8-byte (S16) aligned -> plain vector loads;
+// edge blocks take clamped scalar loads + selects.
+template <bool INTERIOR, int FMT>
+__device__ __forceinline__ RawQuad load_raw(const void* __restrict__ samples, const BlkCtx& c, int j) {
+  RawQuad r;
+  if constexpr (INTERIOR) {
+    if constexpr (FMT == AFX_FMT_F32) {
+      const float* base = (const float*)samples + c.sample_base + j;
+      const float4 q = *reinterpret_cast<const float4*>(base);
+      r.y0 = q.x; r.y1 = q.y; r.y2 = q.z; r.y3 = q.w;
+      r.prev = base[-1];
+    } else {
+      const int16_t* base = (const int16_t*)samples + c.sample_base + j;
+      const short4 q = *reinterpret_cast<const short4*>(base);
+      const float sc = 1.0f / 32768.0f;
+      r.y0 = q.x * sc; r.y1 = q.y * sc; r.y2 = q.z * sc; r.y3 = q.w * sc;
+      r.prev = base[-1] * sc;
+    }
+  } else {
+    const int lo = c.have_lo, hi = c.have_hi - 1;          // hi >= lo: clips have >= 2 samples
+    auto at = [&](int jj) {
+      const int jc = jj < lo ? lo : (jj > hi ? hi : jj);
+      const float v = ld_sample(samples, FMT, c.sample_base + jc);
+      return (jj == jc) ? v : 0.f;
+    };
+    r.prev = at(j - 1); r.y0 = at(j); r.y1 = at(j + 1); r.y2 = at(j + 2); r.y3 = at(j + 3);
+  }
+  return r;
+}
+
+// pre-emphasis (as lfilter does it) + trim mask of one quad -> 4 staged samples
+__device__ __forceinline__ float4 stage_quad(const RawQuad& r, const void* __restrict__ samples, int fmt,
+                                             const BlkCtx& c, int j, bool pre, float b1) {
+  float v0 = r.y0, v1 = r.y1, v2 = r.y2, v3 = r.y3;
+  if (pre) {
+    v0 = preemph1(r.y0, r.prev, b1); v1 = preemph1(r.y1, r.y0, b1);
+    v2 = preemph1(r.y2, r.y1, b1); v3 = preemph1(r.y3, r.y2, b1);
+    const int e0 = c.have_lo - j;         // position of the clip's sample 0 inside this quad
+    if (e0 >= 0 && e0 < 4) {              // librosa's zi = 2*y[0] - y[1]
+      const float z = preemph0(ld_sample(samples, fmt, c.clip_off), ld_sample(samples, fmt, c.clip_off + 1));
+      if (e0 == 0) v0 = z; else if (e0 == 1) v1 = z; else if (e0 == 2) v2 = z; else v3 = z;
+    }
+  }
+  const unsigned span = (unsigned)(c.keep_hi - c.keep_lo), d = (unsigned)(j - c.keep_lo);
+  float4 o;
+  o.x = (d < span) ? v0 : 0.f;
+  o.y = (d + 1u < span) ? v1 : 0.f;
+  o.z = (d + 2u < span) ? v2 : 0.f;
+  o.w = (d + 3u < span) ? v3 : 0.f;
+  return o;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Power-spectrum buffer PB[bin][17]: frame f of bin k at k*17 + f.  The per-frame column
+// write (64 consecutive bins, fixed f) walks banks in steps of 17 -> conflict-free; the
+// mel stage reads 4 consecutive bins x 16 frames per wave -> one 2-way overlap at most.
 
 template <int NFFT>
 __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const void* __restrict__ samples,
-                                                   const ClipDesc* __restrict__ clips,
                                                    ClipInfo* __restrict__ info,
-                                                   const int2* __restrict__ blocks, int nblocks,
+                                                   const BlockDesc* __restrict__ blocks, int nblocks,
                                                    DevTables tb, KParams kp,
                                                    float* __restrict__ logmel,
                                                    float* __restrict__ rms_rows) {
   using C = FC<NFFT>;
   using S = Sched<NFFT>;
   constexpr int N2 = C::N2, NB = C::NB, LPF = C::LPF, P = C::P, FPW = C::FPW;
+  constexpr int MAXCH = (NFFT * 5 + 1023) / 1024;    // 1024-sample chunks a thread prefetches (hop <= n_fft/4)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hop = kp.hop, M = kp.n_mels;
-  const LdsLayout L = lds_layout(NFFT, hop, tb.ntaps, M);
+  const LdsLayout L = lds_layout(NFFT, hop);
   float* const S_ = smem + L.s;
   float* const PB = smem + L.pb;
-  float* const MW = smem + L.mw;
-  int* const MT = reinterpret_cast<int*>(smem + L.mt);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lif = lane % LPF, fsub = lane / LPF;
-  float2* const EX = reinterpret_cast<float2*>(smem + L.ex) + (wave * FPW + fsub) * C::EXN;
+  constexpr bool FAST = (NFFT == 1024);
+  constexpr int EXSTRIDE = FAST ? N2 : C::EXN;
+  float2* const EX = reinterpret_cast<float2*>(smem + L.ex) + (wave * FPW + fsub) * EXSTRIDE;
+  float2* const WT = reinterpret_cast<float2*>(smem + L.tab);          // FAST only
+  float2* const PT = WT + N2;
 
-  // ---- once per workgroup: sparse-mel tables -> LDS; per-lane tables -> registers
-  for (int i = tid; i < tb.ntaps; i += 256) MW[i] = tb.taps[i];
-  for (int i = tid; i < M; i += 256) {
-    MT[i] = tb.mel_k0[i]; MT[M + i] = tb.mel_n4[i]; MT[2 * M + i] = tb.mel_wo[i];
-  }
-  float2 wreg[P], preg[P];
+  // ---- once per workgroup: zero the pad rows of PB; per-lane tables -> registers (or LDS)
+  for (int i = tid; i < kPbPadRows * kPbStride; i += 256) PB[NB * kPbStride + i] = 0.f;
+  float2 wreg[FAST ? 1 : P], preg[FAST ? 1 : P];
+  int maddr[P];                       // exchange-buffer slot of the mirror bin Z[N2 - k]
   {
     const float2* w2 = reinterpret_cast<const float2*>(tb.window);
     const float2* p2 = reinterpret_cast<const float2*>(tb.post);
+    if constexpr (FAST) {
+      for (int i = tid; i < N2; i += 256) { WT[i] = w2[i]; PT[i] = p2[i]; }
+    }
 #pragma unroll
-    for (int u = 0; u < P; ++u) { wreg[u] = w2[lif + LPF * u]; preg[u] = p2[lif + LPF * u]; }
+    for (int u = 0; u < P; ++u) {
+      const int k = lif + LPF * u;
+      const int km = (N2 - k) & (N2 - 1);
+      if constexpr (FAST) maddr[u] = km ^ ((km >> 3) & 7) ^ (((km >> 6) & 1) << 3);
+      else { wreg[u] = w2[k]; preg[u] = p2[k]; maddr[u] = expad(km); }
+    }
   }
+  // FAST: slot swizzle sw(a) = a ^ ((a>>3)&7) ^ (((a>>6)&1)<<3) makes every exchange access of the
+  // 8x8x8 schedule bank-conflict-free; per lane it collapses to four bases:
+  //   pass-1 write 8j+r -> A1 ^ r;  pass-2 write -> A2 ^ 9r;  read / last write j+64r -> (r odd ? B1 : B0) + 64r
+  const int swA1 = (8 * lane) ^ (lane & 7) ^ (((lane >> 3) & 1) << 3);
+  const int swB0 = lane ^ ((lane >> 3) & 7), swB1 = swB0 ^ 8;
+  const int swA2 = 64 * (lane >> 3) + 8 * ((lane >> 3) & 1) + (lane & 7);
   constexpr int NT2 = NTW<typename S::P2>::v, NT3 = NTW<typename S::P3>::v, NT4 = NTW<typename S::P4>::v;
   float2 tw2[NT2 > 0 ? NT2 : 1], tw3[NT3 > 0 ? NT3 : 1], tw4[NT4 > 0 ? NT4 : 1];
   {
@@ -374,188 +486,359 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
     S::P3::load_tw(t2, lif, tw3);
     if constexpr (NT4 > 0) S::P4::load_tw(t2, lif, tw4);
   }
+  // mel: this wave's first two filter groups (all of them when n_mels <= 128) stay in registers
+  const int f16 = lane & 15, q4 = lane >> 4;
+  int4 gm0 = make_int4(0, 0, 0, 0), gm1 = make_int4(0, 0, 0, 0);
+  float4 cf0 = make_float4(0.f, 0.f, 0.f, 0.f), cf1 = cf0;
+  float ko0 = 0.f, ko1 = 0.f;
+  if (wave < tb.n_groups) {
+    gm0 = tb.mel_grp[tb.mel_order[wave]];
+    cf0 = tb.mel_coef[gm0.w * 16 + f16]; ko0 = tb.mel_koff[gm0.w * 16 + f16];
+  }
+  if (wave + kWaves < tb.n_groups) {
+    gm1 = tb.mel_grp[tb.mel_order[wave + kWaves]];
+    cf1 = tb.mel_coef[gm1.w * 16 + f16]; ko1 = tb.mel_koff[gm1.w * 16 + f16];
+  }
+
   const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
   const float b1 = kp.preemph_b1;
+  const int fmt = kp.fmt;
   const int slen = (kFramesPerBlock - 1) * hop + NFFT;
   const bool hop_even = (hop & 1) == 0;
+
+  // A block's 64-byte descriptor is fetched as one dword per lane (VMEM, so that it does not
+  // share a wait counter with the LDS traffic) two blocks ahead and resolved with readlanes.
+  auto fetch_desc = [&](int b) -> int {
+    const int bb = b < nblocks ? b : nblocks - 1;
+    return reinterpret_cast<const int*>(blocks + bb)[lane & 15];
+  };
+  auto resolve = [&](int w, int b) -> BlkCtx {
+    BlkCtx c;
+    auto rl = [&](int i) { return __builtin_amdgcn_readlane(w, i); };
+    auto rl64 = [&](int i) { return (int64_t)(((uint64_t)(uint32_t)rl(i + 1) << 32) | (uint32_t)rl(i)); };
+    c.sample_base = rl64(0); c.frame_slot = rl64(2); c.clip_off = rl64(4);
+    c.keep_lo = rl(6); c.keep_hi = rl(7); c.have_lo = rl(8); c.have_hi = rl(9);
+    c.clip = rl(10); c.t0 = rl(11); c.T = rl(12);
+    c.active = (b < nblocks) && rl(13) != 0;
+    c.interior = ((c.sample_base & 3) == 0) && ((slen & 3) == 0) && c.have_lo <= -1 && c.have_hi >= slen;
+    return c;
+  };
+
+  RawQuad pf[MAXCH];
+  BlkCtx cur = resolve(fetch_desc(blockIdx.x), blockIdx.x);
+  int dnext = fetch_desc(blockIdx.x + gridDim.x);
+  // chunk c of a thread covers staged samples j = 4*tid + 1024*c .. +3; indices past the block are
+  // clamped (loaded, never stored) so that no load sits under a per-lane branch
+  const int jlast = ((slen + 3) & ~3) - 4;
+  auto prefetch = [&](const BlkCtx& bc) {
+#define AFX_PF_LOOP(INTERIOR, FMT)                                                                  \
+    _Pragma("unroll") for (int c = 0; c < MAXCH; ++c) {                                             \
+      const int j = tid * 4 + c * 1024;                                                             \
+      pf[c] = load_raw<INTERIOR, FMT>(samples, bc, j < jlast ? j : jlast);                          \
+    }
+    if (fmt == AFX_FMT_F32) {
+      if (bc.interior) { AFX_PF_LOOP(true, AFX_FMT_F32) } else { AFX_PF_LOOP(false, AFX_FMT_F32) }
+    } else {
+      if (bc.interior) { AFX_PF_LOOP(true, AFX_FMT_S16) } else { AFX_PF_LOOP(false, AFX_FMT_S16) }
+    }
+#undef AFX_PF_LOOP
+  };
+  if (cur.active && !(kp.flags & 0x100)) prefetch(cur);
   __syncthreads();
 
   for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
-    const int2 bd = blocks[b];
-    const int clip = bd.x, t0 = bd.y * kFramesPerBlock;
-    const int T = info[clip].T;
-    if (info[clip].status != AFX_CLIP_OK || t0 >= T) continue;     // uniform per workgroup
-    const int64_t cstart = info[clip].start, cend = info[clip].end;
-    const ClipDesc cd = clips[clip];
-    const int64_t N = cd.len;
-
-    // ---- stage the hop-strided sample block: pre-emphasis + trim mask, once per sample
-    const int64_t g0 = cstart + (int64_t)t0 * hop - NFFT / 2;
-    for (int j = tid * 4; j < slen; j += 1024) {
-      const int64_t i = g0 + j;
-      float y[4], prev;
-      const bool fast = (i >= 1) && (i + 3 < N) && (((cd.off + i) & 3) == 0);
-      if (fast) {
-        if (kp.fmt == AFX_FMT_F32) {
-          const float* base = (const float*)samples + cd.off;
-          const float4 q = *reinterpret_cast<const float4*>(base + i);
-          y[0] = q.x; y[1] = q.y; y[2] = q.z; y[3] = q.w;
-          prev = base[i - 1];
-        } else {
-          const int16_t* base = (const int16_t*)samples + cd.off;
-          const short4 q = *reinterpret_cast<const short4*>(base + i);
-          const float sc = 1.0f / 32768.0f;
-          y[0] = q.x * sc; y[1] = q.y * sc; y[2] = q.z * sc; y[3] = q.w * sc;
-          prev = base[i - 1] * sc;
-        }
-      } else {
+    // ---- stage block b from the prefetched registers: pre-emphasis + trim mask, once per sample
+    // (0x100/0x200/0x400: timing-only ablation switches (AFX_DEBUG_SKIP), results invalid)
+    if (cur.active && !(kp.flags & 0x100)) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int64_t ii = i + e;
-          y[e] = (ii >= 0 && ii < N) ? ld_sample(samples, kp.fmt, cd.off + ii) : 0.f;
-        }
-        prev = (i - 1 >= 0 && i - 1 < N) ? ld_sample(samples, kp.fmt, cd.off + i - 1) : 0.f;
+      for (int c = 0; c < MAXCH; ++c) {
+        const int j = tid * 4 + c * 1024;
+        if (j < slen) *reinterpret_cast<float4*>(S_ + j) = stage_quad(pf[c], samples, fmt, cur, j, pre, b1);
       }
-      float o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int64_t ii = i + e;
-        float v = y[e];
-        if (pre) {
-          v = preemph1(y[e], e == 0 ? prev : y[e - 1], b1);
-          if (ii == 0) v = preemph0(y[e], ld_sample(samples, kp.fmt, cd.off + 1));
-        }
-        o[e] = (ii >= cstart && ii < cend) ? v : 0.f;
-      }
-      *reinterpret_cast<float4*>(S_ + j) = make_float4(o[0], o[1], o[2], o[3]);
+      for (int j = tid * 4 + MAXCH * 1024; j < slen; j += 1024)       // hop > n_fft/4: not prefetched
+        *reinterpret_cast<float4*>(S_ + j) = stage_quad(
+            fmt == AFX_FMT_F32 ? load_raw<false, AFX_FMT_F32>(samples, cur, j) : load_raw<false, AFX_FMT_S16>(samples, cur, j),
+            samples, fmt, cur, j, pre, b1);
     }
     __syncthreads();
+
+    const BlkCtx nxt = resolve(dnext, b + gridDim.x);
+    dnext = fetch_desc(b + 2 * gridDim.x);
 
     // ---- per frame: window -> rFFT -> power spectrum (+ RMS of the unwindowed frame)
+    if (cur.active && !(kp.flags & 0x200)) {
+      if constexpr (FAST) {
+        // two frames (A, B) in flight per wave; they take turns on the wave's single exchange image,
+        // so each one's LDS round trip hides under the other's butterflies
 #pragma unroll 1
-    for (int it = 0; it < C::ITERS; ++it) {
-      const int fl = (it * kWaves + wave) * FPW + fsub;      // frame within the block
-      const float* Sf = S_ + fl * hop;
-      float2 v[P];
-      float ss = 0.f;
+        for (int pr = 0; pr < 2; ++pr) {
+          const int flA = wave * 4 + 2 * pr;
+          const float* SA = S_ + flA * hop;
+          const float* SB = SA + hop;
+          float2 vA[8], vB[8];
+          float ssA = 0.f, ssB = 0.f;
+          {
+            float2 xa[8], xb[8], ww[8];
+            if (hop_even) {
 #pragma unroll
-      for (int u = 0; u < P; ++u) {
-        const int a = lif + LPF * u;
-        float2 x;
-        if (hop_even) x = *reinterpret_cast<const float2*>(Sf + 2 * a);
-        else { x.x = Sf[2 * a]; x.y = Sf[2 * a + 1]; }
-        ss += x.x * x.x; ss += x.y * x.y;
-        v[u] = make_float2(x.x * wreg[u].x, x.y * wreg[u].y);
-      }
+              for (int u = 0; u < 8; ++u) {
+                xa[u] = *reinterpret_cast<const float2*>(SA + 2 * (lane + 64 * u));
+                xb[u] = *reinterpret_cast<const float2*>(SB + 2 * (lane + 64 * u));
+              }
+            } else {
 #pragma unroll
-      for (int o = LPF / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-      if (lif == 0 && t0 + fl < T) rms_rows[cd.frame_base + t0 + fl] = sqrtf(ss / (float)NFFT);
+              for (int u = 0; u < 8; ++u) {
+                const int a = 2 * (lane + 64 * u);
+                xa[u].x = SA[a]; xa[u].y = SA[a + 1]; xb[u].x = SB[a]; xb[u].y = SB[a + 1];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ww[u] = WT[lane + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              ssA += xa[u].x * xa[u].x; ssA += xa[u].y * xa[u].y;
+              ssB += xb[u].x * xb[u].x; ssB += xb[u].y * xb[u].y;
+              vA[u] = make_float2(xa[u].x * ww[u].x, xa[u].y * ww[u].y);
+              vB[u] = make_float2(xb[u].x * ww[u].x, xb[u].y * ww[u].y);
+            }
+          }
+          ssA = wave_sum(ssA); ssB = wave_sum(ssB);
+          if (lane == 0) {
+            if (cur.t0 + flA < cur.T) rms_rows[cur.frame_slot + flA] = sqrtf(ssA / (float)NFFT);
+            if (cur.t0 + flA + 1 < cur.T) rms_rows[cur.frame_slot + flA + 1] = sqrtf(ssB / (float)NFFT);
+          }
+          // pass 1 (radix 8, no twiddles) + exchange
+          dft<8>(vA); dft<8>(vB);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) EX[swA1 ^ r] = vA[r];
+          AFX_CBARRIER();
+#pragma unroll
+          for (int r = 0; r < 8; ++r) vA[r] = EX[((r & 1) ? swB1 : swB0) + 64 * r];
+          AFX_CBARRIER();
+#pragma unroll
+          for (int r = 0; r < 8; ++r) EX[swA1 ^ r] = vB[r];
+          AFX_CBARRIER();
+#pragma unroll
+          for (int r = 0; r < 8; ++r) vB[r] = EX[((r & 1) ? swB1 : swB0) + 64 * r];
+          AFX_CBARRIER();
+          // pass 2
+#pragma unroll
+          for (int r = 1; r < 8; ++r) vA[r] = cmul(vA[r], tw2[r - 1]);
+          dft<8>(vA);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) EX[swA2 ^ (9 * r)] = vA[r];
+          AFX_CBARRIER();
+#pragma unroll
+          for (int r = 0; r < 8; ++r) vA[r] = EX[((r & 1) ? swB1 : swB0) + 64 * r];
+          AFX_CBARRIER();
+#pragma unroll
+          for (int r = 1; r < 8; ++r) vB[r] = cmul(vB[r], tw2[r - 1]);
+          dft<8>(vB);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) EX[swA2 ^ (9 * r)] = vB[r];
+          AFX_CBARRIER();
+#pragma unroll
+          for (int r = 0; r < 8; ++r) vB[r] = EX[((r & 1) ? swB1 : swB0) + 64 * r];
+          AFX_CBARRIER();
+          // pass 3: outputs land on the lane's own bins k = lane + 64 r; publish them for the mirror
+          // reads Z[N2-k]; then the real-FFT split and the power spectrum.  B's pass 3 runs under A's
+          // mirror-read latency.
+          float* const pcol = PB + lane * kPbStride + flA;
+          float2 pw[8];             // split twiddles; read once for both frames (LDS reads must not
+#pragma unroll                  // sit between the PB stores: the compiler would serialise them)
+          for (int u = 0; u < 8; ++u) pw[u] = PT[lane + 64 * u];
+          auto split_store = [&](const float2 (&v)[8], const float2 (&m)[8], int col) {
+            float pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const float2 w = pw[u];
+              const float2 z = v[u], mm = m[u];
+              const float e2r = z.x + mm.x, e2i = z.y - mm.y, o2r = z.y + mm.y, o2i = mm.x - z.x;
+              const float xr = e2r + w.x * o2r - w.y * o2i, xi = e2i + w.x * o2i + w.y * o2r;
+              pv[u] = 0.25f * (xr * xr + xi * xi);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pcol[64 * u * kPbStride + col] = pv[u];
+            if (lane == 0) { const float ny = v[0].x - v[0].y; pcol[N2 * kPbStride + col] = ny * ny; }
+          };
+          {
+            float2 mA[8];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) vA[r] = cmul(vA[r], tw3[r - 1]);
+            dft<8>(vA);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) EX[((r & 1) ? swB1 : swB0) + 64 * r] = vA[r];
+            AFX_CBARRIER();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mA[u] = EX[maddr[u]];
+            AFX_CBARRIER();
+#pragma unroll
+            for (int r = 1; r < 8; ++r) vB[r] = cmul(vB[r], tw3[r - 1]);
+            dft<8>(vB);
+            split_store(vA, mA, 0);
+          }
+          {
+            float2 mB[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) EX[((r & 1) ? swB1 : swB0) + 64 * r] = vB[r];
+            AFX_CBARRIER();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mB[u] = EX[maddr[u]];
+            AFX_CBARRIER();
+            split_store(vB, mB, 1);
+          }
+          AFX_CBARRIER();
+        }
+      } else {
+#pragma unroll 1
+      for (int it = 0; it < C::ITERS; ++it) {
+        const int fl = (wave * C::ITERS + it) * FPW + fsub;      // frame within the block
+        const float* Sf = S_ + fl * hop;
+        float2 v[P];
+        float ss = 0.f;
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const int a = lif + LPF * u;
+          float2 x;
+          if (hop_even) x = *reinterpret_cast<const float2*>(Sf + 2 * a);
+          else { x.x = Sf[2 * a]; x.y = Sf[2 * a + 1]; }
+          ss += x.x * x.x; ss += x.y * x.y;
+          v[u] = make_float2(x.x * wreg[u].x, x.y * wreg[u].y);
+        }
+        if constexpr (LPF == 64) ss = wave_sum(ss);
+        else {
+#pragma unroll
+          for (int o = LPF / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+        }
+        if (lif == 0 && cur.t0 + fl < cur.T) rms_rows[cur.frame_slot + fl] = sqrtf(ss / (float)NFFT);
 
-      S::P1::run(v, nullptr, EX, lif);
-      S::P2::run(v, tw2, EX, lif);
-      S::P3::run(v, tw3, EX, lif);
-      if constexpr (NT4 > 0) S::P4::run(v, tw4, EX, lif);
+        S::P1::run(v, nullptr, EX, lif);
+        S::P2::run(v, tw2, EX, lif);
+        S::P3::run(v, tw3, EX, lif);
+        if constexpr (NT4 > 0) S::P4::run(v, tw4, EX, lif);
 
-      // real-FFT split: X[k] from Z[k] and Z[N2-k]; EX now holds Z in natural order
+        // real-FFT split: X[k] from Z[k] and Z[N2-k]; EX now holds Z in natural order
+        float* const pcol = PB + lif * kPbStride + fl;
 #pragma unroll
-      for (int u = 0; u < P; ++u) {
-        const int k = lif + LPF * u;
-        const float2 z = v[u];
-        const float2 m = EX[expad((N2 - k) & (N2 - 1))];
-        const float e2r = z.x + m.x, e2i = z.y - m.y;
-        const float o2r = z.y + m.y, o2i = m.x - z.x;
-        const float2 w = preg[u];
-        const float xr = e2r + w.x * o2r - w.y * o2i;
-        const float xi = e2i + w.x * o2i + w.y * o2r;
-        PB[pbidx(k, fl)] = 0.25f * (xr * xr + xi * xi);
-        if (u == 0 && lif == 0) { const float ny = z.x - z.y; PB[pbidx(N2, fl)] = ny * ny; }
+        for (int u = 0; u < P; ++u) {
+          const float2 z = v[u];
+          const float2 m = EX[maddr[u]];
+          const float e2r = z.x + m.x, e2i = z.y - m.y;
+          const float o2r = z.y + m.y, o2i = m.x - z.x;
+          const float2 w = preg[u];
+          const float xr = e2r + w.x * o2r - w.y * o2i;
+          const float xi = e2i + w.x * o2i + w.y * o2r;
+          pcol[LPF * u * kPbStride] = 0.25f * (xr * xr + xi * xi);
+          if (u == 0 && lif == 0) { const float ny = z.x - z.y; pcol[N2 * kPbStride] = ny * ny; }
+        }
+        AFX_CBARRIER();
       }
-      AFX_CBARRIER();
+      }
     }
+    // ---- issue the next block's sample loads; they land under the mel phase (issued here rather
+    // than before the FFT so that the raw quads are not live across the register-hungry FFT phase)
+    if (nxt.active && !(kp.flags & 0x100)) prefetch(nxt);
     __syncthreads();
 
-    // ---- sparse mel + dB: lane = (frame f, tap quarter q); four filters per step
-    {
-      const int f = lane & 15, q = lane >> 4;
-      const bool valid = (t0 + f) < T;
+    // ---- mel filterbank + dB on the matrix pipe: D[16 filters][16 frames] += A[16x4] * B[4 bins x 16 frames]
+    // (exact f32 MFMA over the non-zero 16x4 blocks of librosa.filters.mel; the A operand -- the
+    // filter triangles -- is evaluated per lane, see MelBlocks in afx_internal.h)
+    if (cur.active && !(kp.flags & 0x400)) {
+      const bool valid = (cur.t0 + f16) < cur.T;
       float lmax = -INFINITY;
-      float* tile = logmel + (cd.frame_base + t0) * (int64_t)M;
-      const int nq = M >> 2;
-      for (int it = 0; it * kWaves < nq; ++it) {
-        const int qd = it * kWaves + ((it & 1) ? (kWaves - 1 - wave) : wave);
-        if (qd >= nq) continue;
-        float acc[4];
+      float* tile = logmel + cur.frame_slot * (int64_t)M;
+      auto mel_group = [&](const int4 gm, const float4 cf, const float ko) {
+        const int row0 = gm.x + q4;
+        float kf = (float)q4 + ko;                       // k - kc of this lane's bin, exact
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // 8 blocks (32 bins) per step: the 8 B-operand reads are issued together and two accumulators
+        // alternate, so neither the LDS latency nor the MFMA dependency serialises the chain.  Blocks
+        // past the group's range contribute nothing: their triangle weights are 0 and rows past the
+        // Nyquist bin are the zero pad rows (row index clamped onto them).
+        for (int bk = 0; bk < gm.y; bk += 8) {
+          float pb[8];
 #pragma unroll
-        for (int jf = 0; jf < 4; ++jf) {
-          const int m = qd * 4 + jf;
-          const int k0 = __builtin_amdgcn_readfirstlane(MT[m]);
-          const int n4 = __builtin_amdgcn_readfirstlane(MT[M + m]);
-          const int wo = __builtin_amdgcn_readfirstlane(MT[2 * M + m]);
-          float a = 0.f;
-          for (int i = 0; i < n4; ++i) {
-            int kk = k0 + 4 * i + q;
-            kk = kk < NB ? kk : NB - 1;
-            a += MW[wo + 4 * i + q] * PB[pbidx(kk, f)];
+          for (int i = 0; i < 8; ++i) {
+            int row = row0 + 4 * (bk + i);
+            row = row < NB + kPbPadRows - 1 ? row : NB + kPbPadRows - 1;
+            pb[i] = PB[row * kPbStride + f16];
           }
-          acc[jf] = a;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float lo = fmaf(cf.y, kf, cf.x), hi = fmaf(cf.w, kf, cf.z);
+            const float w = __builtin_amdgcn_fmed3f(0.f, lo, hi);     // max(0, min(lo, hi))
+            if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc0, 0, 0, 0);
+            kf += 4.0f;
+          }
         }
-        // reduce-scatter over the four quarters: quarter q ends with filter 4*qd + q
-        const bool hi2 = (q & 2) != 0, hi1 = (q & 1) != 0;
-        const float s0 = hi2 ? acc[0] : acc[2], k0_ = hi2 ? acc[2] : acc[0];
-        const float s1 = hi2 ? acc[1] : acc[3], k1_ = hi2 ? acc[3] : acc[1];
-        const float a0 = k0_ + __shfl_xor(s0, 32);
-        const float a1 = k1_ + __shfl_xor(s1, 32);
-        const float sn = hi1 ? a0 : a1, kn = hi1 ? a1 : a0;
-        const float tot = kn + __shfl_xor(sn, 16);
-        // 10*log10(max(amin, mel)) ; v_log_f32 is log2
-        const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, tot));
-        if (valid) {
-          tile[(qd * 4 + q) * 16 + f] = Lv;
-          lmax = fmaxf(lmax, Lv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = gm.w * 16 + q4 * 4 + r;
+          // 10*log10(max(amin, mel)); v_log_f32 is log2
+          const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc0[r] + acc1[r]));
+          if (valid && m < M) {
+            tile[m * 16 + f16] = Lv;
+            lmax = fmaxf(lmax, Lv);
+          }
         }
+      };
+      if (wave < tb.n_groups) mel_group(gm0, cf0, ko0);
+      if (wave + kWaves < tb.n_groups) mel_group(gm1, cf1, ko1);
+      for (int gi = wave + 2 * kWaves; gi < tb.n_groups; gi += kWaves) {    // n_mels > 128
+        const int4 gm = tb.mel_grp[tb.mel_order[gi]];
+        mel_group(gm, tb.mel_coef[gm.w * 16 + f16], tb.mel_koff[gm.w * 16 + f16]);
       }
       lmax = wave_max(lmax);
-      if (lane == 0 && lmax > -INFINITY) atomicMax(&info[clip].lmax_ord, f2ord(lmax));
+      if (lane == 0 && lmax > -INFINITY) atomicMax(&info[cur.clip].lmax_ord, f2ord(lmax));
     }
-    // no barrier needed here: the next staging only writes S_ (dead since the barrier above),
-    // and PB is rewritten only after the next iteration's first barrier.
+    // no barrier here: the next staging writes only S_ (dead since the barrier above) and PB is
+    // rewritten only after the next iteration's first barrier.
+    cur = nxt;
   }
 }
 
 // ---------------------------------------------------------------------------
-// k_dct: clamp at (clip max - top_db), ortho DCT-II; thread = frame
+// k_dct: clamp at (clip max - top_db), ortho DCT-II on the matrix pipe.
+// One wave per 16-frame log-mel tile: the tile's [mel][16 frames] layout is exactly the
+// MFMA B-operand order, so each k-step is one coalesced 256-byte load.
 // ---------------------------------------------------------------------------
-template <int KMAX>
+template <int NCG>
 __global__ __launch_bounds__(256) void k_dct(const ClipDesc* __restrict__ clips,
                                              const ClipInfo* __restrict__ info,
-                                             const float* __restrict__ dct, KParams kp,
+                                             const float* __restrict__ dctA, KParams kp,
                                              const float* __restrict__ logmel,
                                              float* __restrict__ mfcc) {
   const int clip = blockIdx.y;
   const ClipInfo ci = info[clip];
   if (ci.status != AFX_CLIP_OK) return;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= ci.T) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t0 = (blockIdx.x * 4 + wave) * 16;
+  if (t0 >= ci.T) return;
   const ClipDesc cd = clips[clip];
-  const int M = kp.n_mels, K = kp.n_mfcc;
+  const int M = kp.n_mels, K = kp.n_mfcc, NI = M >> 2;
   const float theta = ord2f(ci.lmax_ord) - kp.top_db;
-  const bool valid = t < ci.T;
-  const int tt = valid ? t : ci.T - 1;
-  const float* tile = logmel + (cd.frame_base + (tt & ~15)) * (int64_t)M + (tt & 15);
-  float acc[KMAX];
+  const int f = lane & 15, q = lane >> 4;
+  const float* tile = logmel + (cd.frame_base + t0) * (int64_t)M + lane;   // (4i + q)*16 + f = 64 i + lane
+  f32x4 acc[NCG];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
-  for (int m = 0; m < M; ++m) {
-    const float Lc = fmaxf(tile[m * 16], theta);
-    // dct is zero-padded to KMAX rows on the device, so no k < K test in the hot loop
+  for (int c = 0; c < NCG; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int i = 0; i < NI; ++i) {
+    const float Lc = fmaxf(tile[i * 64], theta);
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) acc[k] += dct[k * M + m] * Lc;
+    for (int c = 0; c < NCG; ++c)
+      acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(dctA[((int64_t)c * NI + i) * 64 + lane], Lc, acc[c], 0, 0, 0);
   }
-  if (valid) {
-    float* out = mfcc + cd.frame_base * (int64_t)K + t;
+  if (t0 + f < ci.T) {
+    float* out = mfcc + cd.frame_base * (int64_t)K + t0 + f;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-      if (k < K) out[(int64_t)k * cd.tpad] = acc[k];
+    for (int c = 0; c < NCG; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = c * 16 + q * 4 + r;
+        if (k < K) out[(int64_t)k * cd.tpad] = acc[c][r];
+      }
   }
 }
 
@@ -665,16 +948,16 @@ hipError_t launch_trim_blocks(hipStream_t s, const void* samples, const ClipDesc
 }
 
 hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum,
-                              int n_clips, const KParams& kp) {
-  hipLaunchKernelGGL(k_trim_decide, dim3(n_clips), dim3(256), 0, s, clips, info, bsum, kp);
+                              BlockDesc* blocks, int n_clips, const KParams& kp) {
+  hipLaunchKernelGGL(k_trim_decide, dim3(n_clips), dim3(256), 0, s, clips, info, bsum, blocks, kp);
   return hipGetLastError();
 }
 
 template <int NFFT>
-static hipError_t launch_frames_t(hipStream_t s, const void* samples, const ClipDesc* clips, ClipInfo* info,
-                                  const int2* blocks, int nblocks, const DevTables& tb, const KParams& kp,
+static hipError_t launch_frames_t(hipStream_t s, const void* samples, ClipInfo* info,
+                                  const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
                                   float* logmel, float* rms_rows, int grid) {
-  const size_t lds = frames_lds_bytes(NFFT, kp.hop, tb.ntaps, kp.n_mels);
+  const size_t lds = frames_lds_bytes(NFFT, kp.hop);
   static bool attr_set[64] = {};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -685,31 +968,37 @@ static hipError_t launch_frames_t(hipStream_t s, const void* samples, const Clip
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(k_frames<NFFT>, dim3(grid), dim3(256), lds, s, samples, clips, info, blocks, nblocks,
+  hipLaunchKernelGGL(k_frames<NFFT>, dim3(grid), dim3(256), lds, s, samples, info, blocks, nblocks,
                      tb, kp, logmel, rms_rows);
   return hipGetLastError();
 }
 
-hipError_t launch_frames(hipStream_t s, const void* samples, const ClipDesc* clips, ClipInfo* info,
-                         const int2* blocks, int nblocks, const DevTables& tb, const KParams& kp,
+hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
+                         const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
                          float* logmel, float* rms_rows, int grid) {
   switch (kp.n_fft) {
-    case 256:  return launch_frames_t<256>(s, samples, clips, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
-    case 512:  return launch_frames_t<512>(s, samples, clips, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
-    case 1024: return launch_frames_t<1024>(s, samples, clips, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
-    case 2048: return launch_frames_t<2048>(s, samples, clips, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
+    case 256:  return launch_frames_t<256>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
+    case 512:  return launch_frames_t<512>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
+    case 1024: return launch_frames_t<1024>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
+    case 2048: return launch_frames_t<2048>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
     default: return hipErrorInvalidValue;
   }
 }
 
 hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
                       const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax) {
-  dim3 grid((max_tmax + 255) / 256, n_clips);
-  const int K = kp.n_mfcc;
-  if (K <= 16) hipLaunchKernelGGL(k_dct<16>, grid, dim3(256), 0, s, clips, info, tb.dct, kp, logmel, mfcc);
-  else if (K <= 32) hipLaunchKernelGGL(k_dct<32>, grid, dim3(256), 0, s, clips, info, tb.dct, kp, logmel, mfcc);
-  else if (K <= 64) hipLaunchKernelGGL(k_dct<64>, grid, dim3(256), 0, s, clips, info, tb.dct, kp, logmel, mfcc);
-  else hipLaunchKernelGGL(k_dct<128>, grid, dim3(256), 0, s, clips, info, tb.dct, kp, logmel, mfcc);
+  dim3 grid(((max_tmax + 15) / 16 + 3) / 4, n_clips);
+  switch (tb.n_cgroups) {
+    case 1: hipLaunchKernelGGL(k_dct<1>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 2: hipLaunchKernelGGL(k_dct<2>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 3: hipLaunchKernelGGL(k_dct<3>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 4: hipLaunchKernelGGL(k_dct<4>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 5: hipLaunchKernelGGL(k_dct<5>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 6: hipLaunchKernelGGL(k_dct<6>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 7: hipLaunchKernelGGL(k_dct<7>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 8: hipLaunchKernelGGL(k_dct<8>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 // norm='ortho') underneath librosa.feature.mfcc
 // (audio_feature_extraction_toolkit/core/feature_extractor.py:127-134).
 // Everything is evaluated in double and rounded where librosa rounds.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -47,11 +48,11 @@ static double mel_to_hz(double m) {
   return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
 }
 
-static void build_mel_dense(const afx_params& p, std::vector<float>& W) {
+static void build_mel_dense(const afx_params& p, std::vector<float>& W, std::vector<double>& mel_f) {
   const int M = p.n_mels, NB = p.n_fft / 2 + 1;
   const double fmax = (double)p.sr / 2.0;
   // mel_frequencies(n_mels + 2): np.linspace in the mel domain
-  std::vector<double> mel_f(M + 2);
+  mel_f.assign(M + 2, 0.0);
   const double m0 = hz_to_mel(0.0), m1 = hz_to_mel(fmax);
   const double step = (m1 - m0) / (double)(M + 1);
   for (int i = 0; i < M + 2; ++i) mel_f[i] = mel_to_hz(i == M + 1 ? m1 : (double)i * step + m0);
@@ -71,22 +72,65 @@ static void build_mel_dense(const afx_params& p, std::vector<float>& W) {
   }
 }
 
-static void build_mel_sparse(const afx_params& p, const std::vector<float>& W, MelSparse& s) {
+static void build_mel_blocks(const afx_params& p, const std::vector<float>& W,
+                             const std::vector<double>& mel_f, MelBlocks& s) {
   const int M = p.n_mels, NB = p.n_fft / 2 + 1;
-  s.k0.assign(M, 0); s.ntap4.assign(M, 0); s.woff.assign(M, 0); s.taps.clear();
-  for (int m = 0; m < M; ++m) {
-    int first = -1, last = -1;
-    for (int k = 0; k < NB; ++k)
-      if (W[(size_t)m * NB + k] != 0.f) { if (first < 0) first = k; last = k; }
-    s.woff[m] = (int32_t)s.taps.size();
-    if (first < 0) continue;                        // empty filter: mel = 0
-    const int nnz = last - first + 1;
-    const int n4 = (nnz + 3) / 4;
-    s.k0[m] = first; s.ntap4[m] = n4;
-    for (int i = 0; i < n4 * 4; ++i)
-      s.taps.push_back(i < nnz ? W[(size_t)m * NB + first + i] : 0.f);
+  const int G = (M + 15) / 16;
+  s.n_groups = G; s.grp.clear(); s.order.clear(); s.coef.clear(); s.koff.clear();
+  const double delta = 1.0 / ((double)p.n_fft * (1.0 / (double)p.sr));
+  int first_blk = 0;
+  std::vector<int> nblk(G, 0);
+  for (int g = 0; g < G; ++g) {
+    int kmin = NB, kmax = -1;
+    for (int m = 16 * g; m < std::min(M, 16 * g + 16); ++m)
+      for (int k = 0; k < NB; ++k)
+        if (W[(size_t)m * NB + k] != 0.f) { kmin = std::min(kmin, k); kmax = std::max(kmax, k); }
+    int nb = 0;
+    if (kmax >= 0) nb = (kmax - kmin + 1 + 3) / 4; else kmin = 0;
+    nblk[g] = nb;
+    s.grp.push_back(kmin); s.grp.push_back(nb); s.grp.push_back(first_blk); s.grp.push_back(g);
+    for (int i = 0; i < 16; ++i) {
+      const int m = 16 * g + i;
+      if (m >= M) { for (int c = 0; c < 4; ++c) s.coef.push_back(0.f); s.koff.push_back(0.f); continue; }
+      const double fd0 = mel_f[m + 1] - mel_f[m], fd1 = mel_f[m + 2] - mel_f[m + 1];
+      const double en = 2.0 / (mel_f[m + 2] - mel_f[m]);
+      const long kc = std::lround(mel_f[m + 1] / delta);
+      s.coef.push_back((float)(((double)kc * delta - mel_f[m]) * en / fd0));
+      s.coef.push_back((float)(delta * en / fd0));
+      s.coef.push_back((float)((mel_f[m + 2] - (double)kc * delta) * en / fd1));
+      s.coef.push_back((float)(-delta * en / fd1));
+      s.koff.push_back((float)((long)kmin - kc));
+    }
+    first_blk += nb;
   }
-  if (s.taps.empty()) s.taps.push_back(0.f);
+  // balance the groups over the 4 waves: sort by block count, deal snake-wise
+  std::vector<int> idx(G);
+  for (int g = 0; g < G; ++g) idx[g] = g;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return nblk[a] > nblk[b]; });
+  s.order.assign(G, 0);
+  for (int i = 0; i < G; ++i) {
+    const int r = i / 4, w = i % 4;
+    const int src = 4 * r + ((r & 1) ? 3 - w : w);
+    s.order[i] = idx[src < G ? src : i];
+  }
+  // when G is not a multiple of 4 the snake may address past the end; fall back to sorted order
+  std::vector<char> seen(G, 0);
+  bool ok = true;
+  for (int i = 0; i < G; ++i) { if (seen[s.order[i]]) ok = false; seen[s.order[i]] = 1; }
+  if (!ok) for (int i = 0; i < G; ++i) s.order[i] = idx[i];
+}
+
+static void build_dct_blocks(const afx_params& p, const std::vector<float>& D, DctBlocks& d) {
+  const int M = p.n_mels, K = p.n_mfcc;
+  const int C = (K + 15) / 16, NI = M / 4;
+  d.n_cgroups = C;
+  d.A.assign((size_t)C * NI * 64, 0.f);
+  for (int c = 0; c < C; ++c)
+    for (int i = 0; i < NI; ++i)
+      for (int l = 0; l < 64; ++l) {
+        const int k = 16 * c + (l & 15), m = 4 * i + (l >> 4);
+        if (k < K) d.A[((size_t)c * NI + i) * 64 + l] = D[(size_t)k * M + m];
+      }
 }
 
 void build_host_tables(const afx_params& p, HostTables& t) {
@@ -96,14 +140,16 @@ void build_host_tables(const afx_params& p, HostTables& t) {
     const double c = std::cos(2.0 * kPi * (double)n / (double)N);
     t.window[n] = (float)(p.window == AFX_WINDOW_HANN ? 0.5 - 0.5 * c : 0.54 - 0.46 * c);
   }
-  build_mel_dense(p, t.mel_dense);
-  build_mel_sparse(p, t.mel_dense, t.mel);
+  std::vector<double> mel_f;
+  build_mel_dense(p, t.mel_dense, mel_f);
+  build_mel_blocks(p, t.mel_dense, mel_f, t.mel);
   t.dct.resize((size_t)K * M);
   for (int k = 0; k < K; ++k) {
     const double s = k == 0 ? std::sqrt(1.0 / M) : std::sqrt(2.0 / M);
     for (int m = 0; m < M; ++m)
       t.dct[(size_t)k * M + m] = (float)(s * std::cos(kPi * k * (2.0 * m + 1.0) / (2.0 * M)));
   }
+  build_dct_blocks(p, t.dct, t.dctb);
   t.tw.resize((size_t)2 * N2); t.post.resize((size_t)2 * N2);
   for (int n = 0; n < N2; ++n) {
     const double a = -2.0 * kPi * (double)n / (double)N2;

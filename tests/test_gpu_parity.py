@@ -139,7 +139,7 @@ def test_ragged_batch_with_edge_cases(plans):
         ref = oracle_stats(c, sr, 1024, 256, 13)
         check_frames(out["frames"][i], ref, f"ragged{i}")
         check_stats(out["stats"][i], ref, 13, f"ragged{i}")
-    assert out["stats"][1][0] == pytest.approx(-100.0 * np.sqrt(128), rel=1e-6)
+    assert out["stats"][1][0] == pytest.approx(-100.0 * np.sqrt(128), rel=1e-5)
     # unaligned packing (offsets not multiples of 4) takes the scalar load path: same results
     offs2 = np.concatenate([[1], 1 + np.cumsum(lengths + 1)[:-1]]).astype(np.int64)
     buf2 = np.zeros(int(offs2[-1] + lengths[-1] + 8), np.float32)
