@@ -336,7 +336,7 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
 
   KParams kp = pl->kp;
   kp.flags = flags; kp.fmt = fmt;
-  if (const char* dbg = getenv("AFX_DEBUG_SKIP")) kp.flags |= (atoi(dbg) & 7) << 8;   // timing ablation only
+  if (const char* dbg = getenv("AFX_DEBUG_SKIP")) kp.flags |= (atoi(dbg) & 31) << 8;   // timing ablation only
   const ClipDesc* d_clips = (const ClipDesc*)pl->clips.p;
   ClipInfo* d_info = (ClipInfo*)pl->info.p;
 

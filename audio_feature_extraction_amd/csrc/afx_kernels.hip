@@ -26,6 +26,14 @@ namespace afx {
 // small helpers
 // ---------------------------------------------------------------------------
 #define AFX_CBARRIER() asm volatile("" ::: "memory")
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would wait for
+// the sample prefetch (and the log-mel stores) at every phase boundary.
+#define AFX_LDS_BARRIER()                                   \
+  do {                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();                           \
+    asm volatile("" ::: "memory");                          \
+  } while (0)
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
   uint32_t u = __float_as_uint(f);
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
 #undef AFX_PF_LOOP
   };
   if (cur.active && !(kp.flags & 0x100)) prefetch(cur);
-  __syncthreads();
+  AFX_LDS_BARRIER();
 
   for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
     // ---- stage block b from the prefetched registers: pre-emphasis + trim mask, once per sample
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
             fmt == AFX_FMT_F32 ? load_raw<false, AFX_FMT_F32>(samples, cur, j) : load_raw<false, AFX_FMT_S16>(samples, cur, j),
             samples, fmt, cur, j, pre, b1);
     }
-    __syncthreads();
+    AFX_LDS_BARRIER();
 
     const BlkCtx nxt = resolve(dnext, b + gridDim.x);
     dnext = fetch_desc(b + 2 * gridDim.x);
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
     // ---- issue the next block's sample loads; they land under the mel phase (issued here rather
     // than before the FFT so that the raw quads are not live across the register-hungry FFT phase)
     if (nxt.active && !(kp.flags & 0x100)) prefetch(nxt);
-    __syncthreads();
+    AFX_LDS_BARRIER();
 
     // ---- mel filterbank + dB on the matrix pipe: D[16 filters][16 frames] += A[16x4] * B[4 bins x 16 frames]
     // (exact f32 MFMA over the non-zero 16x4 blocks of librosa.filters.mel; the A operand -- the
@@ -755,7 +763,7 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
         // alternate, so neither the LDS latency nor the MFMA dependency serialises the chain.  Blocks
         // past the group's range contribute nothing: their triangle weights are 0 and rows past the
         // Nyquist bin are the zero pad rows (row index clamped onto them).
-        for (int bk = 0; bk < gm.y; bk += 8) {
+        for (int bk = 0; bk < ((kp.flags & 0x1000) ? 0 : gm.y); bk += 8) {
           float pb[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -778,7 +786,7 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
           // 10*log10(max(amin, mel)); v_log_f32 is log2
           const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc0[r] + acc1[r]));
           if (valid && m < M) {
-            tile[m * 16 + f16] = Lv;
+            if (!(kp.flags & 0x800)) tile[m * 16 + f16] = Lv;
             lmax = fmaxf(lmax, Lv);
           }
         }
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
         mel_group(gm, tb.mel_coef[gm.w * 16 + f16], tb.mel_koff[gm.w * 16 + f16]);
       }
       lmax = wave_max(lmax);
-      if (lane == 0 && lmax > -INFINITY) atomicMax(&info[cur.clip].lmax_ord, f2ord(lmax));
+      if (lane == 0 && lmax > -INFINITY && !(kp.flags & 0x800)) atomicMax(&info[cur.clip].lmax_ord, f2ord(lmax));
     }
     // no barrier here: the next staging writes only S_ (dead since the barrier above) and PB is
     // rewritten only after the next iteration's first barrier.

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/cpu_ref.py).
+
+The reference itself cannot run here (it imports librosa, which is not installed and not
+vendored; there is no network), and its own test file for the hot-path class is empty, so
+these vectors are produced by the oracle -- the numpy/scipy restatement of the librosa
+0.11.0 semantics the reference calls -- and pin the oracle (and through it the HIP path)
+against drift.  "Parity unpinned" in the sense of the task statement: no reference-made
+vector exists for this path.
+
+Inputs are stored as generator arguments (audio_feature_extraction_amd.synth.make_clip);
+outputs are the float32-flow results plus the float64 truth of the statistics.
+Run from the repo root:  python oracle/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from audio_feature_extraction_amd.synth import make_clip  # noqa: E402
+from oracle import cpu_ref as R  # noqa: E402
+
+CASES = [
+    # name, sr, n_fft, hop, n_mfcc, clip index, seconds, speechy
+    ("cfg2_plain", 22050, 1024, 256, 13, 100, 1.0, False),
+    ("cfg2_speechy", 22050, 1024, 256, 13, 101, 1.5, True),
+    ("cfg3_plain", 16000, 512, 128, 40, 102, 1.0, False),
+    ("cfg3_speechy", 16000, 512, 128, 40, 103, 1.5, True),
+    ("cfg5_plain", 44100, 2048, 512, 20, 104, 1.0, False),
+    ("cfg5_speechy", 44100, 2048, 512, 20, 105, 1.5, True),
+]
+STAT_KEYS = ("mfcc_mean", "mfcc_std", "mfcc_delta_mean", "mfcc_delta2_mean",
+             "energy_mean", "energy_std", "energy_range")
+
+
+def main():
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    for name, sr, n_fft, hop, K, idx, secs, speechy in CASES:
+        y = make_clip(idx, sr, secs, speechy=speechy)
+        a = R.extract_stats(y, sr=sr, frame_length=n_fft, hop_length=hop, n_mfcc=K, return_frames=True)
+        b = R.extract_stats(y, sr=sr, frame_length=n_fft, hop_length=hop, n_mfcc=K, dtype=np.float64)
+        rec = {
+            "params": np.array([sr, n_fft, hop, K, idx, int(speechy)], np.int64),
+            "seconds": np.float64(secs),
+            "y_head": y[:16],                                   # guards the generator itself
+            "y_pre_head": R.preemphasis(y, 0.97)[:16],
+            "trim": np.array(a["trim"], np.int64),
+            "mfcc": a["mfcc"].astype(np.float32),
+            "rms": a["rms"].astype(np.float32),
+        }
+        for k in STAT_KEYS:
+            rec[k] = np.asarray(a[k], np.float32)
+            rec[k + "_f64"] = np.asarray(b[k], np.float64)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+        print(name, "frames", a["mfcc"].shape[1], "trim", a["trim"])
+
+
+if __name__ == "__main__":
+    main()
