@@ -35,27 +35,38 @@ CLIPS_PER_GPU = 1000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def _cpu_clip_job(idx: int) -> int:
-    """One clip through the oracle, single-threaded (worker of the all-core pool too)."""
-    import numpy as np  # noqa: F401
+_POOL_CLIPS = None
+
+
+def _pool_init(first: int, per_worker: int) -> None:
+    """Each pool worker pre-generates its own clips so that generation is not timed."""
+    global _POOL_CLIPS
+    import multiprocessing as mp
     from audio_feature_extraction_amd.synth import make_clip
     from oracle import cpu_ref
-    y = make_clip(idx, SR, SECONDS)
+    ident = (mp.current_process()._identity or (1,))[0]
+    _POOL_CLIPS = [make_clip(first + (ident * 131 + i) % 1000, SR, SECONDS) for i in range(per_worker)]
+    cpu_ref.extract_stats(_POOL_CLIPS[0], sr=SR, frame_length=N_FFT, hop_length=HOP, n_mfcc=N_MFCC)   # warm
+
+
+def _pool_job(k: int) -> int:
+    from oracle import cpu_ref
+    y = _POOL_CLIPS[k % len(_POOL_CLIPS)]
     out = cpu_ref.extract_stats(y, sr=SR, frame_length=N_FFT, hop_length=HOP, n_mfcc=N_MFCC)
     return 1 + (out["trim"][1] - out["trim"][0]) // HOP
 
 
-def cpu_baseline(n_single: int, n_pool: int) -> dict:
-    """Times the CPU oracle: one core (BLAS pinned to 1 thread), then a spawn-pool over
-    cpu_count-1 workers (the reference's only parallel harness is a Pool over files)."""
-    import numpy as np
-    from audio_feature_extraction_amd.synth import make_clip
+def cpu_baseline(samples, offsets, lengths, n_single: int, n_pool: int) -> dict:
+    """Times the CPU oracle on clips of the GPU workload itself: one core (BLAS pinned to one
+    thread) over the first n_single clips, then a spawn-pool over cpu_count-1 workers (the
+    reference's only parallel harness is a multiprocessing.Pool over files)."""
     from oracle import cpu_ref
     try:
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
-    clips = [make_clip(i, SR, SECONDS) for i in range(n_single)]
+    n_single = min(n_single, len(offsets))
+    clips = [samples[offsets[i]: offsets[i] + lengths[i]] for i in range(n_single)]
     frames = 0
 
     def run():
@@ -75,23 +86,24 @@ def cpu_baseline(n_single: int, n_pool: int) -> dict:
     dt = time.perf_counter() - t0
     res = {
         "value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": f"{n_single} of the {CLIPS_PER_GPU} clips (10 s @22050 Hz, 1024/256/13), "
-                  f"numpy/scipy oracle, single thread, {dt:.1f} s",
+        "sample": f"first {n_single} of the {len(offsets)} clips of this workload (10 s @22050 Hz, 1024/256/13), "
+                  f"numpy/scipy oracle (pre-emphasis, trim, MFCC + deltas, RMS, statistics; no file load, no pYIN), "
+                  f"single thread, {dt:.1f} s",
         "host_cpus": os.cpu_count(),
     }
     ncpu = os.cpu_count() or 1
     if n_pool > 0 and ncpu > 2:
         import multiprocessing as mp
-        workers = max(1, min(ncpu - 1, 32))
+        workers = max(1, min(ncpu - 1, 64))
         os.environ.setdefault("OMP_NUM_THREADS", "1")
         os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
-        with mp.get_context("spawn").Pool(workers) as pool:
-            pool.map(_cpu_clip_job, range(workers))           # warm the workers (imports)
+        with mp.get_context("spawn").Pool(workers, initializer=_pool_init, initargs=(0, 4)) as pool:
+            pool.map(_pool_job, range(workers))                 # make sure every worker is up
             t0 = time.perf_counter()
-            fr = sum(pool.map(_cpu_clip_job, range(n_pool), chunksize=1))
+            fr = sum(pool.map(_pool_job, range(n_pool), chunksize=4))
             dt2 = time.perf_counter() - t0
         res["all_cores"] = {"value": fr / dt2, "unit": "frames/s", "cores": workers,
-                            "sample": f"{n_pool} clips over a {workers}-process pool, {dt2:.1f} s"}
+                            "sample": f"{n_pool} clip passes over a {workers}-process spawn pool, {dt2:.1f} s"}
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
@@ -109,8 +121,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU (default: the BASELINE config)")
-    ap.add_argument("--cpu-clips", type=int, default=24, help="clips timed on one CPU core (0 = skip the CPU baseline)")
-    ap.add_argument("--cpu-pool-clips", type=int, default=96)
+    ap.add_argument("--cpu-clips", type=int, default=1000, help="clips timed on one CPU core (0 = skip the CPU baseline)")
+    ap.add_argument("--cpu-pool-clips", type=int, default=8000)
     ap.add_argument("--no-timing-events", action="store_true")
     args = ap.parse_args()
 
@@ -121,15 +133,20 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     distributed = world > 1
 
+    import numpy as np
+    from audio_feature_extraction_amd.synth import make_batch
+
+    n_clips = args.clips
+    workers = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    samples, offsets, lengths = make_batch(n_clips, SR, SECONDS, first_index=rank * n_clips, workers=workers)
+
     # CPU baseline first (rank 0, N=1 only), before this process touches the GPU
     cpu = None
     if rank == 0 and world == 1 and args.cpu_clips > 0:
-        cpu = cpu_baseline(args.cpu_clips, args.cpu_pool_clips)
+        cpu = cpu_baseline(samples, offsets, lengths, args.cpu_clips, args.cpu_pool_clips)
 
-    import numpy as np
     import torch
     from audio_feature_extraction_amd import _native as N
-    from audio_feature_extraction_amd.synth import make_batch
 
     if not torch.cuda.is_available() or N.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -138,10 +155,6 @@ def main() -> None:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    n_clips = args.clips
-    workers = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
-    samples, offsets, lengths = make_batch(n_clips, SR, SECONDS, first_index=rank * n_clips, workers=workers)
 
     ctx = N.Context(local_rank)
     plan = N.Plan(ctx, N.make_params(SR, N_FFT, HOP, N_MFCC))
@@ -194,8 +207,21 @@ def main() -> None:
         if kt is not None and kt["frames"][1] > 0:
             avg_ms = kt["frames"][0] / kt["frames"][1]
             achieved = frames_per_step * 4.0 * HOP / (avg_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) cannot be
+            # collected inside this process; the committed profile of this same command supplies them
+            traffic, tsrc = None, None
+            try:
+                import glob
+                cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+                if cand and n_clips == CLIPS_PER_GPU:
+                    with open(cand[-1]) as fh:
+                        traffic = json.load(fh)["hbm_bytes_per_launch"]
+                    tsrc = os.path.relpath(cand[-1], ROOT)
+            except Exception:
+                traffic = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_frames<1024>",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                    "algorithmic_bytes_per_launch": frames_per_step * 4 * HOP, "kernel": "k_frames<1024>",
                     "avg_launch_ms": avg_ms,
                     "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in kt.items()}}
         line = {
