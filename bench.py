@@ -150,13 +150,19 @@ def main() -> None:
 
     if not torch.cuda.is_available() or N.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; AFX_BENCH_BACKEND=gloo lets the N>1 path be rehearsed on a 1-GPU box
+    backend = os.environ.get("AFX_BENCH_BACKEND", "nccl")
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=backend)
 
-    ctx = N.Context(local_rank)
+    ctx = N.Context(device)
     plan = N.Plan(ctx, N.make_params(SR, N_FFT, HOP, N_MFCC))
     dbuf = N.DeviceBuffer(ctx, samples.nbytes)
     dbuf.upload(samples)
@@ -196,7 +202,7 @@ def main() -> None:
     kt = plan.timings() if not args.no_timing_events else None
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
