@@ -3,6 +3,7 @@
 // See include/afx.h for the contract and the reference call sites replaced.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -40,7 +41,7 @@ struct afx_plan {
   HostTables ht;
   DevTables dt{};
   std::vector<void*> table_allocs;
-  DevBuf samples, clips, info, blocks, bsum, logmel, rms, mfcc, stats, frames, frame_offs;
+  DevBuf samples, clips, info, blocks, bsum, logmel, rms, mfcc, stats, frames, frame_offs, stamps;
   // cached per-batch descriptors
   std::vector<int64_t> c_off, c_len;
   std::vector<ClipDesc> h_clips;
@@ -194,19 +195,23 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
   const HostTables& t = pl->ht;
   const int4* grp4 = nullptr;
   const float4* coef4 = nullptr;
+  const int4* items4 = nullptr;
   if ((rc = upload(pl, t.window.data(), t.window.size(), &pl->dt.window)) != AFX_OK ||
       (rc = upload(pl, t.tw.data(), t.tw.size(), &pl->dt.tw)) != AFX_OK ||
       (rc = upload(pl, t.post.data(), t.post.size(), &pl->dt.post)) != AFX_OK ||
       (rc = upload(pl, reinterpret_cast<const float4*>(t.mel.coef.data()), t.mel.coef.size() / 4, &coef4)) != AFX_OK ||
       (rc = upload(pl, t.mel.koff.data(), t.mel.koff.size(), &pl->dt.mel_koff)) != AFX_OK ||
       (rc = upload(pl, reinterpret_cast<const int4*>(t.mel.grp.data()), t.mel.grp.size() / 4, &grp4)) != AFX_OK ||
-      (rc = upload(pl, t.mel.order.data(), t.mel.order.size(), &pl->dt.mel_order)) != AFX_OK ||
+      (rc = upload(pl, reinterpret_cast<const int4*>(t.mel.items.data()), t.mel.items.size() / 4, &items4)) != AFX_OK ||
       (rc = upload(pl, t.dctb.A.data(), t.dctb.A.size(), &pl->dt.dctA)) != AFX_OK) {
     afx_plan_destroy(pl);
     return rc;
   }
   pl->dt.mel_grp = grp4;
   pl->dt.mel_coef = coef4;
+  pl->dt.mel_items = items4;
+  for (int w = 0; w < 4; ++w) pl->dt.mel_item_cnt[w] = t.mel.item_cnt[w];
+  pl->dt.mel_n_slots = t.mel.n_slots;
   pl->dt.n_groups = t.mel.n_groups;
   pl->dt.n_cgroups = t.dctb.n_cgroups;
   hipDeviceProp_t prop;
@@ -222,7 +227,7 @@ extern "C" void afx_plan_destroy(afx_plan* pl) {
   for (void* d : pl->table_allocs) (void)hipFree(d);
   release(pl->samples); release(pl->clips); release(pl->info); release(pl->blocks); release(pl->bsum);
   release(pl->logmel); release(pl->rms); release(pl->mfcc); release(pl->stats); release(pl->frames);
-  release(pl->frame_offs);
+  release(pl->frame_offs); release(pl->stamps);
   if (pl->ev_ready)
     for (int k = 0; k < AFX_K_COUNT; ++k) { (void)hipEventDestroy(pl->ev[k][0]); (void)hipEventDestroy(pl->ev[k][1]); }
   delete pl;
@@ -336,7 +341,7 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
 
   KParams kp = pl->kp;
   kp.flags = flags; kp.fmt = fmt;
-  if (const char* dbg = getenv("AFX_DEBUG_SKIP")) kp.flags |= (atoi(dbg) & 31) << 8;   // timing ablation only
+  if (const char* dbg = getenv("AFX_DEBUG_SKIP")) kp.flags |= (atoi(dbg) & 127) << 8;   // timing ablation only
   const ClipDesc* d_clips = (const ClipDesc*)pl->clips.p;
   ClipInfo* d_info = (ClipInfo*)pl->info.p;
 
@@ -345,8 +350,38 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
   TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, n, kp));
   if (pl->nblocks > 0) {
     const int grid = std::min(pl->nblocks, pl->n_cu * 2);
+    unsigned long long* d_stamps = nullptr;
+    const bool want_stamps = getenv("AFX_DEBUG_STAMPS") != nullptr;     // diagnostic build of k_frames
+    if (want_stamps) {
+      if ((rc = ensure(pl->stamps, (size_t)grid * kWaves * kStampPhases * 8)) != AFX_OK) return rc;
+      d_stamps = (unsigned long long*)pl->stamps.p;
+      HIP_TRY(hipMemsetAsync(d_stamps, 0, (size_t)grid * kWaves * kStampPhases * 8, s));
+    }
     TIMED(AFX_K_FRAMES, launch_frames(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks,
-                                      pl->dt, kp, (float*)pl->logmel.p, (float*)pl->rms.p, grid));
+                                      pl->dt, kp, (float*)pl->logmel.p, (float*)pl->rms.p, grid, d_stamps));
+    if (want_stamps) {
+      std::vector<unsigned long long> h((size_t)grid * kWaves * kStampPhases);
+      HIP_TRY(hipMemcpyAsync(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      static const char* names[kStampPhases] = {"stage", "bar1", "fft", "prefetch", "bar2", "mel", "bar3", "melfin"};
+      double tot[kStampPhases] = {}, wv[kWaves][kStampPhases] = {};
+      for (int g = 0; g < grid; ++g)
+        for (int w = 0; w < kWaves; ++w)
+          for (int ph = 0; ph < kStampPhases; ++ph) {
+            const double v = (double)h[((size_t)g * kWaves + w) * kStampPhases + ph];
+            tot[ph] += v; wv[w][ph] += v;
+          }
+      const double per = (double)pl->nblocks * kWaves;      // cycles per block per wave
+      fprintf(stderr, "[afx stamps] cycles per block (avg over waves):");
+      double all = 0;
+      for (int ph = 0; ph < kStampPhases; ++ph) { fprintf(stderr, " %s=%.0f", names[ph], tot[ph] / per); all += tot[ph] / per; }
+      fprintf(stderr, " total=%.0f\n", all);
+      for (int w = 0; w < kWaves; ++w) {
+        fprintf(stderr, "[afx stamps]   wave %d:", w);
+        for (int ph = 0; ph < kStampPhases; ++ph) fprintf(stderr, " %s=%.0f", names[ph], wv[w][ph] / pl->nblocks);
+        fprintf(stderr, "\n");
+      }
+    }
     TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax));
   }
   TIMED(AFX_K_STATS, launch_stats(s, d_clips, d_info, kp, (const float*)pl->mfcc.p, (const float*)pl->rms.p,

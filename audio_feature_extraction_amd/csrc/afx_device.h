@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "afx.h"
+#include "afx_consts.h"
 
 namespace afx {
 
@@ -53,7 +54,9 @@ struct DevTables {
   const float4* mel_coef; // per (group, row): a_lo, b_lo, a_hi, b_hi of the filter's triangle
   const float* mel_koff;  // per (group, row): kmin - kc
   const int4* mel_grp;   // per 16-filter group: kmin, nblk, first block, group id
-  const int32_t* mel_order;
+  const int4* mel_items;  // [4 waves][8 items][2 x int4]: group, b0, nb, role | slot, nslots, 0, 0
+  int32_t mel_item_cnt[4];
+  int32_t mel_n_slots;    // LDS partial-sum slots in use (0: no group is split)
   const float* dctA;     // DCT-II rows as MFMA A images
   int32_t n_groups;      // ceil(n_mels / 16)
   int32_t n_cgroups;     // ceil(n_mfcc / 16)
@@ -77,7 +80,8 @@ hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* in
                               BlockDesc* blocks, int n_clips, const KParams& kp);
 hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
                          const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
-                         float* logmel, float* rms_rows, int grid);
+                         float* logmel, float* rms_rows, int grid, unsigned long long* stamps = nullptr);
+constexpr int kStampPhases = 8;
 hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
                       const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax);
 hipError_t launch_stats(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const KParams& kp,

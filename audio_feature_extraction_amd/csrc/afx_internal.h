@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "afx.h"
+#include "afx_consts.h"
 
 namespace afx {
 
@@ -19,7 +20,13 @@ namespace afx {
 struct MelBlocks {
   int32_t n_groups = 0;
   std::vector<int32_t> grp;     // 4 ints per group: kmin, nblk, first block, group id
-  std::vector<int32_t> order;   // processing order, dealt snake-wise over the 4 waves
+  // k_frames' mel schedule: the groups' block ranges cut into work items balanced over the 4 waves.
+  // A group much larger than a wave's fair share is split along its bins; all but one of its parts
+  // ("writers") park their partial 16x16 sums in an LDS slot, the last ("reader") adds them.
+  // 8 ints per item: group, first block, n blocks, role (0 whole, 1 writer, 2 reader), slot, n slots, 0, 0
+  std::vector<int32_t> items;   // [4 waves][kMelMaxItems][8]
+  int32_t item_cnt[4] = {0, 0, 0, 0};
+  int32_t n_slots = 0;
   std::vector<float> coef;      // per (group, row): a_lo, b_lo, a_hi, b_hi
   std::vector<float> koff;      // per (group, row): kmin - kc  (k - kc = koff + 4*blk + q)
 };

@@ -257,7 +257,7 @@ constexpr int kPbPadRows = 3;   // zero rows past the Nyquist bin: mel blocks ar
 // exchange image without padding, window / split twiddles in LDS, two frames in flight per wave.
 __host__ __device__ inline bool fast1024(int n_fft) { return n_fft == 1024; }
 
-struct LdsLayout { int s, ex, pb, tab, total; };   // float offsets
+struct LdsLayout { int s, ex, pb, tab, rb, total; };   // float offsets
 __host__ __device__ inline LdsLayout lds_layout(int n_fft, int hop) {
   const int N2 = n_fft / 2;
   const int lpf = (N2 / 8 >= 64) ? 64 : N2 / 8;
@@ -268,7 +268,8 @@ __host__ __device__ inline LdsLayout lds_layout(int n_fft, int hop) {
   L.ex = L.s + round4((kFramesPerBlock - 1) * hop + n_fft);
   L.pb = L.ex + kWaves * fpw * exn * 2;
   L.tab = L.pb + round4((N2 + 1 + kPbPadRows) * kPbStride);
-  L.total = L.tab + (fast1024(n_fft) ? 4 * N2 : 0);      // window[N2] float2 + post[N2] float2
+  L.rb = L.tab + (fast1024(n_fft) ? 4 * N2 : 0);         // window[N2] float2 + post[N2] float2
+  L.total = L.rb + kMelMaxSlots * 256 + (fast1024(n_fft) ? 128 : 0);   // mel partial sums; pass-2 twiddles W64^(c*r), 8x8 float2
   return L;
 }
 
@@ -366,8 +367,10 @@ template <> struct Sched<2048> { using C = FC<2048>; using P1 = Pass<C::N2, C::L
 template <typename PX> struct NTW { static constexpr int v = PX::NTW; };
 template <> struct NTW<void> { static constexpr int v = 0; };
 
-// raw samples of one staged quad (4 consecutive samples + the one before them)
-struct RawQuad { float y0, y1, y2, y3, prev; };
+// Raw samples of one staged quad: the 4 samples (bit pattern of the vector load: float4, or 4 x int16
+// in .x/.y) and the sample before them.  Kept as native vector registers: a struct of five floats made
+// hipcc merge the two loads into an unaligned dwordx4 plus a dword and then shuffle -- and wait -- per quad.
+struct RawQuad { float4 q; float prev; };
 
 struct BlkCtx {          // uniform per workgroup; one BlockDesc resolved into scalars
   int64_t sample_base, frame_slot, clip_off;
@@ -378,24 +381,24 @@ struct BlkCtx {          // uniform per workgroup; one BlockDesc resolved into s
 
 // staged index j -> raw samples j-1 .. j+3 of the block (zeros outside the clip).
 // Branch-free on purpose: a per-lane "load or keep" branch makes hipcc wait vmcnt(0) inside every
-// branch, which serialises the prefetch.  `interior` is uniform per block: every staged sample and
-// its predecessor exist and the quads are 16-byte (F32) / 8-byte (S16) aligned -> plain vector loads;
-// edge blocks take clamped scalar loads + selects.
+// branch, which serialises the prefetch.  `interior` is uniform per block: every staged sample and its
+// predecessor exist and the quads are 16-byte (F32) / 8-byte (S16) aligned -> one plain vector load per
+// quad; the predecessor comes from the neighbouring lane at staging time, so only the wave's first lane
+// needs it from memory: all lanes load that one (wave-uniform) address.  Edge blocks take clamped
+// scalar loads + selects and carry a per-lane predecessor.
 template <bool INTERIOR, int FMT>
-__device__ __forceinline__ RawQuad load_raw(const void* __restrict__ samples, const BlkCtx& c, int j) {
+__device__ __forceinline__ RawQuad load_raw(const void* __restrict__ samples, const BlkCtx& c, int j, int jwave) {
   RawQuad r;
   if constexpr (INTERIOR) {
     if constexpr (FMT == AFX_FMT_F32) {
-      const float* base = (const float*)samples + c.sample_base + j;
-      const float4 q = *reinterpret_cast<const float4*>(base);
-      r.y0 = q.x; r.y1 = q.y; r.y2 = q.z; r.y3 = q.w;
-      r.prev = base[-1];
+      const float* base = (const float*)samples + c.sample_base;
+      r.q = *reinterpret_cast<const float4*>(base + j);
+      r.prev = base[jwave - 1];
     } else {
-      const int16_t* base = (const int16_t*)samples + c.sample_base + j;
-      const short4 q = *reinterpret_cast<const short4*>(base);
-      const float sc = 1.0f / 32768.0f;
-      r.y0 = q.x * sc; r.y1 = q.y * sc; r.y2 = q.z * sc; r.y3 = q.w * sc;
-      r.prev = base[-1] * sc;
+      const int16_t* base = (const int16_t*)samples + c.sample_base;
+      const int2 q = *reinterpret_cast<const int2*>(base + j);
+      r.q = make_float4(__int_as_float(q.x), __int_as_float(q.y), 0.f, 0.f);
+      r.prev = (float)base[jwave - 1] * (1.0f / 32768.0f);
     }
   } else {
     const int lo = c.have_lo, hi = c.have_hi - 1;          // hi >= lo: clips have >= 2 samples
@@ -404,22 +407,37 @@ __device__ __forceinline__ RawQuad load_raw(const void* __restrict__ samples, co
       const float v = ld_sample(samples, FMT, c.sample_base + jc);
       return (jj == jc) ? v : 0.f;
     };
-    r.prev = at(j - 1); r.y0 = at(j); r.y1 = at(j + 1); r.y2 = at(j + 2); r.y3 = at(j + 3);
+    r.prev = at(j - 1);
+    r.q = make_float4(at(j), at(j + 1), at(j + 2), at(j + 3));
   }
   return r;
 }
 
 // pre-emphasis (as lfilter does it) + trim mask of one quad -> 4 staged samples
-__device__ __forceinline__ float4 stage_quad(const RawQuad& r, const void* __restrict__ samples, int fmt,
+template <bool INTERIOR, int FMT>
+__device__ __forceinline__ float4 stage_quad(const RawQuad& r, const void* __restrict__ samples,
                                              const BlkCtx& c, int j, bool pre, float b1) {
-  float v0 = r.y0, v1 = r.y1, v2 = r.y2, v3 = r.y3;
+  float y0, y1, y2, y3, prev;
+  if constexpr (INTERIOR && FMT == AFX_FMT_S16) {
+    const int a = __float_as_int(r.q.x), b = __float_as_int(r.q.y);
+    const float sc = 1.0f / 32768.0f;
+    y0 = (float)(short)(a & 0xffff) * sc; y1 = (float)(short)(a >> 16) * sc;
+    y2 = (float)(short)(b & 0xffff) * sc; y3 = (float)(short)(b >> 16) * sc;
+  } else { y0 = r.q.x; y1 = r.q.y; y2 = r.q.z; y3 = r.q.w; }
+  if constexpr (INTERIOR) {
+    // predecessor = previous lane's last sample (DPP wave_shr:1); lane 0 keeps the loaded one
+    prev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(r.prev), __float_as_int(y3), 0x138, 0xf, 0xf, false));
+  } else prev = r.prev;
+  float v0 = y0, v1 = y1, v2 = y2, v3 = y3;
   if (pre) {
-    v0 = preemph1(r.y0, r.prev, b1); v1 = preemph1(r.y1, r.y0, b1);
-    v2 = preemph1(r.y2, r.y1, b1); v3 = preemph1(r.y3, r.y2, b1);
-    const int e0 = c.have_lo - j;         // position of the clip's sample 0 inside this quad
-    if (e0 >= 0 && e0 < 4) {              // librosa's zi = 2*y[0] - y[1]
-      const float z = preemph0(ld_sample(samples, fmt, c.clip_off), ld_sample(samples, fmt, c.clip_off + 1));
-      if (e0 == 0) v0 = z; else if (e0 == 1) v1 = z; else if (e0 == 2) v2 = z; else v3 = z;
+    v0 = preemph1(y0, prev, b1); v1 = preemph1(y1, y0, b1);
+    v2 = preemph1(y2, y1, b1); v3 = preemph1(y3, y2, b1);
+    if constexpr (!INTERIOR) {            // only edge blocks can hold the clip's sample 0
+      const int e0 = c.have_lo - j;
+      if (e0 >= 0 && e0 < 4) {            // librosa's zi = 2*y[0] - y[1]
+        const float z = preemph0(ld_sample(samples, FMT, c.clip_off), ld_sample(samples, FMT, c.clip_off + 1));
+        if (e0 == 0) v0 = z; else if (e0 == 1) v1 = z; else if (e0 == 2) v2 = z; else v3 = z;
+      }
     }
   }
   const unsigned span = (unsigned)(c.keep_hi - c.keep_lo), d = (unsigned)(j - c.keep_lo);
@@ -437,14 +455,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // write (64 consecutive bins, fixed f) walks banks in steps of 17 -> conflict-free; the
 // mel stage reads 4 consecutive bins x 16 frames per wave -> one 2-way overlap at most.
 
-template <int NFFT>
+// STAMP = true is a separate diagnostic instantiation (AFX_DEBUG_STAMPS): lane 0 of every wave sums
+// s_memtime deltas per phase into `stamps`; the production kernel carries none of it.
+enum { ST_STAGE = 0, ST_BAR1, ST_FFT, ST_PREFETCH, ST_BAR2, ST_MEL, ST_BAR3, ST_MELFIN, ST_COUNT };
+
+template <int NFFT, bool STAMP>
 __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const void* __restrict__ samples,
                                                    ClipInfo* __restrict__ info,
                                                    const BlockDesc* __restrict__ blocks, int nblocks,
                                                    DevTables tb, KParams kp,
                                                    float* __restrict__ logmel,
-                                                   float* __restrict__ rms_rows) {
+                                                   float* __restrict__ rms_rows,
+                                                   unsigned long long* __restrict__ stamps) {
   using C = FC<NFFT>;
+  unsigned long long st_sum[ST_COUNT] = {}, st_prev = 0;
+  auto stamp = [&](int ph) {
+    if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0) only
+      __builtin_amdgcn_sched_barrier(0);
+      if (ph >= 0) st_sum[ph] += t - st_prev;
+      st_prev = t;
+    }
+  };
   using S = Sched<NFFT>;
   constexpr int N2 = C::N2, NB = C::NB, LPF = C::LPF, P = C::P, FPW = C::FPW;
   constexpr int MAXCH = (NFFT * 5 + 1023) / 1024;    // 1024-sample chunks a thread prefetches (hop <= n_fft/4)
@@ -461,23 +495,27 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
   float2* const EX = reinterpret_cast<float2*>(smem + L.ex) + (wave * FPW + fsub) * EXSTRIDE;
   float2* const WT = reinterpret_cast<float2*>(smem + L.tab);          // FAST only
   float2* const PT = WT + N2;
+  float2* const T2 = reinterpret_cast<float2*>(smem + L.rb + kMelMaxSlots * 256);   // FAST only
 
   // ---- once per workgroup: zero the pad rows of PB; per-lane tables -> registers (or LDS)
   for (int i = tid; i < kPbPadRows * kPbStride; i += 256) PB[NB * kPbStride + i] = 0.f;
   float2 wreg[FAST ? 1 : P], preg[FAST ? 1 : P];
-  int maddr[P];                       // exchange-buffer slot of the mirror bin Z[N2 - k]
+  int maddr[FAST ? 1 : P];            // exchange-buffer slot of the mirror bin Z[N2 - k] (generic path)
   {
     const float2* w2 = reinterpret_cast<const float2*>(tb.window);
     const float2* p2 = reinterpret_cast<const float2*>(tb.post);
     if constexpr (FAST) {
-      for (int i = tid; i < N2; i += 256) { WT[i] = w2[i]; PT[i] = p2[i]; }
+      // window pre-scaled by 1/2 (exact): the split below then yields X, not 2X, and |X|^2 needs no 0.25
+      for (int i = tid; i < N2; i += 256) { WT[i] = make_float2(0.5f * w2[i].x, 0.5f * w2[i].y); PT[i] = p2[i]; }
+      // pass-2 twiddles W_64^(c*r), c = lane & 7: 64 values, read per frame pair instead of 14 registers per lane
+      if (tid < 64) T2[tid] = reinterpret_cast<const float2*>(tb.tw)[(tid >> 3) * (tid & 7) * (N2 / 64)];
     }
+    if constexpr (!FAST) {
 #pragma unroll
-    for (int u = 0; u < P; ++u) {
-      const int k = lif + LPF * u;
-      const int km = (N2 - k) & (N2 - 1);
-      if constexpr (FAST) maddr[u] = km ^ ((km >> 3) & 7) ^ (((km >> 6) & 1) << 3);
-      else { wreg[u] = w2[k]; preg[u] = p2[k]; maddr[u] = expad(km); }
+      for (int u = 0; u < P; ++u) {
+        const int k = lif + LPF * u;
+        wreg[u] = w2[k]; preg[u] = p2[k]; maddr[u] = expad((N2 - k) & (N2 - 1));
+      }
     }
   }
   // FAST: slot swizzle sw(a) = a ^ ((a>>3)&7) ^ (((a>>6)&1)<<3) makes every exchange access of the
@@ -490,22 +528,32 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
   float2 tw2[NT2 > 0 ? NT2 : 1], tw3[NT3 > 0 ? NT3 : 1], tw4[NT4 > 0 ? NT4 : 1];
   {
     const float2* t2 = reinterpret_cast<const float2*>(tb.tw);
-    S::P2::load_tw(t2, lif, tw2);
+    if constexpr (!FAST) S::P2::load_tw(t2, lif, tw2);
     S::P3::load_tw(t2, lif, tw3);
     if constexpr (NT4 > 0) S::P4::load_tw(t2, lif, tw4);
   }
-  // mel: this wave's first two filter groups (all of them when n_mels <= 128) stay in registers
-  const int f16 = lane & 15, q4 = lane >> 4;
-  int4 gm0 = make_int4(0, 0, 0, 0), gm1 = make_int4(0, 0, 0, 0);
-  float4 cf0 = make_float4(0.f, 0.f, 0.f, 0.f), cf1 = cf0;
-  float ko0 = 0.f, ko1 = 0.f;
-  if (wave < tb.n_groups) {
-    gm0 = tb.mel_grp[tb.mel_order[wave]];
-    cf0 = tb.mel_coef[gm0.w * 16 + f16]; ko0 = tb.mel_koff[gm0.w * 16 + f16];
-  }
-  if (wave + kWaves < tb.n_groups) {
-    gm1 = tb.mel_grp[tb.mel_order[wave + kWaves]];
-    cf1 = tb.mel_coef[gm1.w * 16 + f16]; ko1 = tb.mel_koff[gm1.w * 16 + f16];
+  // mel: this wave's first work items (all of them when n_mels <= 128) stay in registers
+  const int f16k = lane & 15;
+  float* const RB = smem + L.rb;
+  const int mel_cnt = __builtin_amdgcn_readfirstlane(
+      tb.mel_item_cnt[0] * (wave == 0) + tb.mel_item_cnt[1] * (wave == 1) +
+      tb.mel_item_cnt[2] * (wave == 2) + tb.mel_item_cnt[3] * (wave == 3));
+  int4 mi_a[kMelRegItems], mi_b[kMelRegItems];       // (group, b0, nb, role), (slot, nslots, kmin, -)
+  float4 mi_cf[kMelRegItems];
+  float mi_ko[kMelRegItems];
+#pragma unroll
+  for (int i = 0; i < kMelRegItems; ++i) {
+    mi_a[i] = make_int4(0, 0, 0, 0); mi_b[i] = make_int4(0, 0, 0, 0);
+    mi_cf[i] = make_float4(0.f, 0.f, 0.f, 0.f); mi_ko[i] = 0.f;
+    if (i < mel_cnt) {
+      // wave-uniform metadata -> SGPRs (the compiler cannot see that tid >> 6 is uniform)
+      auto sg = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+      const int4 a = tb.mel_items[(wave * kMelMaxItems + i) * 2], bb = tb.mel_items[(wave * kMelMaxItems + i) * 2 + 1];
+      mi_a[i] = make_int4(sg(a.x), sg(a.y), sg(a.z), sg(a.w));
+      mi_b[i] = make_int4(sg(bb.x), sg(bb.y), sg(tb.mel_grp[a.x].x), 0);
+      mi_cf[i] = tb.mel_coef[mi_a[i].x * 16 + f16k];
+      mi_ko[i] = tb.mel_koff[mi_a[i].x * 16 + f16k];
+    }
   }
 
   const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
@@ -532,17 +580,50 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
     return c;
   };
 
+  // Log-mel values of the block just finished wait in registers and are stored one iteration later,
+  // right after the staging wait: vmcnt retires in order and counts stores, so stores issued after the
+  // sample prefetch would be drained (1-2 us) by the wait for those samples at the top of the loop.
+  float lmh[kMelRegItems][4];
+  bool pend = false;
+  float pend_lmax = -INFINITY;
+  int64_t pend_slot = 0;
+  int pend_t0 = 0, pend_T = 0, pend_clip = 0;
+  auto flush_logmel = [&]() {
+    if (!pend) return;
+    pend = false;
+    int lane_f = lane;
+    asm volatile("" : "+v"(lane_f));
+    const int f16 = lane_f & 15, q4 = lane_f >> 4;
+    const bool valid = (pend_t0 + f16) < pend_T;
+    float* tile = logmel + pend_slot * (int64_t)M;
+    if (!(kp.flags & 0x800)) {
+#pragma unroll
+      for (int i = 0; i < kMelRegItems; ++i) {
+        if (i < mel_cnt && mi_a[i].w != 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mi_a[i].x * 16 + q4 * 4 + r;
+            if (valid && m < M) tile[m * 16 + f16] = lmh[i][r];
+          }
+        }
+      }
+      const float mx = wave_max(pend_lmax);
+      if (lane_f == 0 && mx > -INFINITY) atomicMax(&info[pend_clip].lmax_ord, f2ord(mx));
+    }
+  };
+
   RawQuad pf[MAXCH];
   BlkCtx cur = resolve(fetch_desc(blockIdx.x), blockIdx.x);
   int dnext = fetch_desc(blockIdx.x + gridDim.x);
   // chunk c of a thread covers staged samples j = 4*tid + 1024*c .. +3; indices past the block are
   // clamped (loaded, never stored) so that no load sits under a per-lane branch
   const int jlast = ((slen + 3) & ~3) - 4;
+  const int jwave0 = (tid & ~63) * 4;          // staged index of this wave's first lane in chunk 0
   auto prefetch = [&](const BlkCtx& bc) {
 #define AFX_PF_LOOP(INTERIOR, FMT)                                                                  \
     _Pragma("unroll") for (int c = 0; c < MAXCH; ++c) {                                             \
-      const int j = tid * 4 + c * 1024;                                                             \
-      pf[c] = load_raw<INTERIOR, FMT>(samples, bc, j < jlast ? j : jlast);                          \
+      const int j = tid * 4 + c * 1024, jw = jwave0 + c * 1024;                                     \
+      pf[c] = load_raw<INTERIOR, FMT>(samples, bc, j < jlast ? j : jlast, jw < jlast ? jw : jlast); \
     }
     if (fmt == AFX_FMT_F32) {
       if (bc.interior) { AFX_PF_LOOP(true, AFX_FMT_F32) } else { AFX_PF_LOOP(false, AFX_FMT_F32) }
@@ -551,24 +632,34 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
     }
 #undef AFX_PF_LOOP
   };
+  auto stage_all = [&](const BlkCtx& bc) {
+#define AFX_ST_LOOP(INTERIOR, FMT)                                                                  \
+    _Pragma("unroll") for (int c = 0; c < MAXCH; ++c) {                                             \
+      const int j = tid * 4 + c * 1024;                                                             \
+      const float4 o = stage_quad<INTERIOR, FMT>(pf[c], samples, bc, j < jlast ? j : jlast, pre, b1); \
+      if (j < slen) *reinterpret_cast<float4*>(S_ + j) = o;                                         \
+    }                                                                                               \
+    for (int j = tid * 4 + MAXCH * 1024; j < slen; j += 1024)  /* hop > n_fft/4: not prefetched */   \
+      *reinterpret_cast<float4*>(S_ + j) = stage_quad<false, FMT>(load_raw<false, FMT>(samples, bc, j, j), samples, bc, j, pre, b1);
+    if (fmt == AFX_FMT_F32) {
+      if (bc.interior) { AFX_ST_LOOP(true, AFX_FMT_F32) } else { AFX_ST_LOOP(false, AFX_FMT_F32) }
+    } else {
+      if (bc.interior) { AFX_ST_LOOP(true, AFX_FMT_S16) } else { AFX_ST_LOOP(false, AFX_FMT_S16) }
+    }
+#undef AFX_ST_LOOP
+  };
   if (cur.active && !(kp.flags & 0x100)) prefetch(cur);
   AFX_LDS_BARRIER();
 
   for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    stamp(-1);
     // ---- stage block b from the prefetched registers: pre-emphasis + trim mask, once per sample
     // (0x100/0x200/0x400: timing-only ablation switches (AFX_DEBUG_SKIP), results invalid)
-    if (cur.active && !(kp.flags & 0x100)) {
-#pragma unroll
-      for (int c = 0; c < MAXCH; ++c) {
-        const int j = tid * 4 + c * 1024;
-        if (j < slen) *reinterpret_cast<float4*>(S_ + j) = stage_quad(pf[c], samples, fmt, cur, j, pre, b1);
-      }
-      for (int j = tid * 4 + MAXCH * 1024; j < slen; j += 1024)       // hop > n_fft/4: not prefetched
-        *reinterpret_cast<float4*>(S_ + j) = stage_quad(
-            fmt == AFX_FMT_F32 ? load_raw<false, AFX_FMT_F32>(samples, cur, j) : load_raw<false, AFX_FMT_S16>(samples, cur, j),
-            samples, fmt, cur, j, pre, b1);
-    }
+    if (cur.active && !(kp.flags & 0x100)) stage_all(cur);
+    flush_logmel();
+    stamp(ST_STAGE);
     AFX_LDS_BARRIER();
+    stamp(ST_BAR1);
 
     const BlkCtx nxt = resolve(dnext, b + gridDim.x);
     dnext = fetch_desc(b + 2 * gridDim.x);
@@ -581,6 +672,8 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
 #pragma unroll 1
         for (int pr = 0; pr < 2; ++pr) {
           const int flA = wave * 4 + 2 * pr;
+          int a1 = swA1, a2 = swA2;              // opaque per iteration: keeps LICM from parking the 16
+          asm volatile("" : "+v"(a1), "+v"(a2)); // XOR-ed exchange addresses in registers for the whole kernel
           const float* SA = S_ + flA * hop;
           const float* SB = SA + hop;
           float2 vA[8], vB[8];
@@ -618,32 +711,35 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
           // pass 1 (radix 8, no twiddles) + exchange
           dft<8>(vA); dft<8>(vB);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) EX[swA1 ^ r] = vA[r];
+          for (int r = 0; r < 8; ++r) EX[a1 ^ r] = vA[r];
           AFX_CBARRIER();
 #pragma unroll
           for (int r = 0; r < 8; ++r) vA[r] = EX[((r & 1) ? swB1 : swB0) + 64 * r];
           AFX_CBARRIER();
 #pragma unroll
-          for (int r = 0; r < 8; ++r) EX[swA1 ^ r] = vB[r];
+          for (int r = 0; r < 8; ++r) EX[a1 ^ r] = vB[r];
           AFX_CBARRIER();
 #pragma unroll
           for (int r = 0; r < 8; ++r) vB[r] = EX[((r & 1) ? swB1 : swB0) + 64 * r];
           AFX_CBARRIER();
           // pass 2
+          float2 t2v[8];
 #pragma unroll
-          for (int r = 1; r < 8; ++r) vA[r] = cmul(vA[r], tw2[r - 1]);
+          for (int r = 1; r < 8; ++r) t2v[r] = T2[(lane & 7) * 8 + r];
+#pragma unroll
+          for (int r = 1; r < 8; ++r) vA[r] = cmul(vA[r], t2v[r]);
           dft<8>(vA);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) EX[swA2 ^ (9 * r)] = vA[r];
+          for (int r = 0; r < 8; ++r) EX[a2 ^ (9 * r)] = vA[r];
           AFX_CBARRIER();
 #pragma unroll
           for (int r = 0; r < 8; ++r) vA[r] = EX[((r & 1) ? swB1 : swB0) + 64 * r];
           AFX_CBARRIER();
 #pragma unroll
-          for (int r = 1; r < 8; ++r) vB[r] = cmul(vB[r], tw2[r - 1]);
+          for (int r = 1; r < 8; ++r) vB[r] = cmul(vB[r], t2v[r]);
           dft<8>(vB);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) EX[swA2 ^ (9 * r)] = vB[r];
+          for (int r = 0; r < 8; ++r) EX[a2 ^ (9 * r)] = vB[r];
           AFX_CBARRIER();
 #pragma unroll
           for (int r = 0; r < 8; ++r) vB[r] = EX[((r & 1) ? swB1 : swB0) + 64 * r];
@@ -663,23 +759,32 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
               const float2 z = v[u], mm = m[u];
               const float e2r = z.x + mm.x, e2i = z.y - mm.y, o2r = z.y + mm.y, o2i = mm.x - z.x;
               const float xr = e2r + w.x * o2r - w.y * o2i, xi = e2i + w.x * o2i + w.y * o2r;
-              pv[u] = 0.25f * (xr * xr + xi * xi);
+              pv[u] = xr * xr + xi * xi;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) pcol[64 * u * kPbStride + col] = pv[u];
-            if (lane == 0) { const float ny = v[0].x - v[0].y; pcol[N2 * kPbStride + col] = ny * ny; }
+            if (lane == 0) { const float ny = 2.0f * (v[0].x - v[0].y); pcol[N2 * kPbStride + col] = ny * ny; }
+          };
+          const int msrc = ((64 - lane) & 63) << 2;           // ds_bpermute byte address of the mirror lane
+          auto mirror = [&](const float2 (&v)[8], float2 (&m)[8]) {
+            // Z[N2 - k] for k = lane + 64u sits in lane 64 - lane, register 7 - u: a crossbar permute,
+            // no LDS image needed.  Lane 0 mirrors onto itself one register up ((8 - u) & 7).
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              m[u].x = __int_as_float(__builtin_amdgcn_ds_bpermute(msrc, __float_as_int(v[7 - u].x)));
+              m[u].y = __int_as_float(__builtin_amdgcn_ds_bpermute(msrc, __float_as_int(v[7 - u].y)));
+            }
+            if (lane == 0) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) m[u] = v[(8 - u) & 7];
+            }
           };
           {
             float2 mA[8];
 #pragma unroll
             for (int r = 1; r < 8; ++r) vA[r] = cmul(vA[r], tw3[r - 1]);
             dft<8>(vA);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) EX[((r & 1) ? swB1 : swB0) + 64 * r] = vA[r];
-            AFX_CBARRIER();
-#pragma unroll
-            for (int u = 0; u < 8; ++u) mA[u] = EX[maddr[u]];
-            AFX_CBARRIER();
+            mirror(vA, mA);
 #pragma unroll
             for (int r = 1; r < 8; ++r) vB[r] = cmul(vB[r], tw3[r - 1]);
             dft<8>(vB);
@@ -687,12 +792,7 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
           }
           {
             float2 mB[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) EX[((r & 1) ? swB1 : swB0) + 64 * r] = vB[r];
-            AFX_CBARRIER();
-#pragma unroll
-            for (int u = 0; u < 8; ++u) mB[u] = EX[maddr[u]];
-            AFX_CBARRIER();
+            mirror(vB, mB);
             split_store(vB, mB, 1);
           }
           AFX_CBARRIER();
@@ -745,65 +845,111 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
     }
     // ---- issue the next block's sample loads; they land under the mel phase (issued here rather
     // than before the FFT so that the raw quads are not live across the register-hungry FFT phase)
+    stamp(ST_FFT);
     if (nxt.active && !(kp.flags & 0x100)) prefetch(nxt);
+    stamp(ST_PREFETCH);
     AFX_LDS_BARRIER();
+    stamp(ST_BAR2);
 
     // ---- mel filterbank + dB on the matrix pipe: D[16 filters][16 frames] += A[16x4] * B[4 bins x 16 frames]
     // (exact f32 MFMA over the non-zero 16x4 blocks of librosa.filters.mel; the A operand -- the
-    // filter triangles -- is evaluated per lane, see MelBlocks in afx_internal.h)
-    if (cur.active && !(kp.flags & 0x400)) {
-      const bool valid = (cur.t0 + f16) < cur.T;
-      float lmax = -INFINITY;
-      float* tile = logmel + cur.frame_slot * (int64_t)M;
-      auto mel_group = [&](const int4 gm, const float4 cf, const float ko) {
-        const int row0 = gm.x + q4;
-        float kf = (float)q4 + ko;                       // k - kc of this lane's bin, exact
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        // 8 blocks (32 bins) per step: the 8 B-operand reads are issued together and two accumulators
-        // alternate, so neither the LDS latency nor the MFMA dependency serialises the chain.  Blocks
-        // past the group's range contribute nothing: their triangle weights are 0 and rows past the
-        // Nyquist bin are the zero pad rows (row index clamped onto them).
-        for (int bk = 0; bk < ((kp.flags & 0x1000) ? 0 : gm.y); bk += 8) {
-          float pb[8];
+    // filter triangles -- is evaluated per lane, see MelBlocks in afx_internal.h).  The block ranges are
+    // cut into work items balanced over the 4 waves; a split group's partial sums meet in an LDS slot.
+    const bool mel_on = cur.active && !(kp.flags & 0x400);
+    // lane index made opaque per block: otherwise LICM hoists every lane-derived address of this phase
+    // out of the block loop and they sit in registers through the (register-bound) FFT phase
+    int lane_m = lane;
+    asm volatile("" : "+v"(lane_m));
+    const int f16 = lane_m & 15, q4 = lane_m >> 4;
+    const bool valid = (cur.t0 + f16) < cur.T;
+    float lmax = -INFINITY;
+    float* tile = logmel + cur.frame_slot * (int64_t)M;
+    auto mel_item = [&](int kmin, int b0, int nb, const float4 cf, const float ko) -> f32x4 {
+      const int row0 = kmin + 4 * b0 + q4;
+      float kf = (float)(q4 + 4 * b0) + ko;                       // k - kc of this lane's bin, exact
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      // 8 blocks (32 bins) per step: the 8 B-operand reads are issued together and two accumulators
+      // alternate, so neither the LDS latency nor the MFMA dependency serialises the chain.  Blocks
+      // past the item's range get zero weight (and rows past the Nyquist bin are the zero pad rows).
+      for (int bk = 0; bk < ((kp.flags & 0x1000) ? 0 : nb); bk += 8) {
+        float pb[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            int row = row0 + 4 * (bk + i);
-            row = row < NB + kPbPadRows - 1 ? row : NB + kPbPadRows - 1;
-            pb[i] = PB[row * kPbStride + f16];
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float lo = fmaf(cf.y, kf, cf.x), hi = fmaf(cf.w, kf, cf.z);
-            const float w = __builtin_amdgcn_fmed3f(0.f, lo, hi);     // max(0, min(lo, hi))
-            if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc1, 0, 0, 0);
-            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc0, 0, 0, 0);
-            kf += 4.0f;
-          }
+        for (int i = 0; i < 8; ++i) {
+          int row = row0 + 4 * (bk + i);
+          row = row < NB + kPbPadRows - 1 ? row : NB + kPbPadRows - 1;
+          pb[i] = (kp.flags & 0x4000) ? 1.0f : PB[row * kPbStride + f16];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = gm.w * 16 + q4 * 4 + r;
-          // 10*log10(max(amin, mel)); v_log_f32 is log2
-          const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc0[r] + acc1[r]));
-          if (valid && m < M) {
-            if (!(kp.flags & 0x800)) tile[m * 16 + f16] = Lv;
-            lmax = fmaxf(lmax, Lv);
-          }
+        for (int i = 0; i < 8; ++i) {
+          const float lo = fmaf(cf.y, kf, cf.x), hi = fmaf(cf.w, kf, cf.z);
+          float w = __builtin_amdgcn_fmed3f(0.f, lo, hi);           // max(0, min(lo, hi))
+          w = (bk + i < nb) ? w : 0.f;                               // the next part of a split group owns those bins
+          if (kp.flags & 0x2000) w = 1.0f;
+          if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc1, 0, 0, 0);
+          else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc0, 0, 0, 0);
+          kf += 4.0f;
         }
-      };
-      if (wave < tb.n_groups) mel_group(gm0, cf0, ko0);
-      if (wave + kWaves < tb.n_groups) mel_group(gm1, cf1, ko1);
-      for (int gi = wave + 2 * kWaves; gi < tb.n_groups; gi += kWaves) {    // n_mels > 128
-        const int4 gm = tb.mel_grp[tb.mel_order[gi]];
-        mel_group(gm, tb.mel_coef[gm.w * 16 + f16], tb.mel_koff[gm.w * 16 + f16]);
       }
-      lmax = wave_max(lmax);
-      if (lane == 0 && lmax > -INFINITY && !(kp.flags & 0x800)) atomicMax(&info[cur.clip].lmax_ord, f2ord(lmax));
+      return acc0 + acc1;
+    };
+    // dst == nullptr: store the tile rows now (table-driven items); otherwise park the four values in
+    // registers -- their global stores are issued next iteration, after the staging wait (see lmh)
+    auto mel_finish = [&](const f32x4 acc, int g, float* dst) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = g * 16 + q4 * 4 + r;
+        // 10*log10(max(amin, mel)); v_log_f32 is log2
+        const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc[r]));
+        if (dst) dst[r] = Lv;
+        if (valid && m < M) {
+          if (!dst && !(kp.flags & 0x800)) tile[m * 16 + f16] = Lv;
+          lmax = fmaxf(lmax, Lv);
+        }
+      }
+    };
+    f32x4 held[kMelRegItems];
+    if (mel_on) {
+#pragma unroll
+      for (int i = 0; i < kMelRegItems; ++i) {
+        if (i < mel_cnt) {
+          held[i] = mel_item(mi_b[i].z, mi_a[i].y, mi_a[i].z, mi_cf[i], mi_ko[i]);
+          if (mi_a[i].w == 0) mel_finish(held[i], mi_a[i].x, lmh[i]);
+          else if (mi_a[i].w == 1) *reinterpret_cast<f32x4*>(RB + mi_b[i].x * 256 + lane_m * 4) = held[i];
+        }
+      }
+      for (int i = kMelRegItems; i < mel_cnt; ++i) {            // n_mels > 128: whole groups, tables re-read
+        const int4 ia = tb.mel_items[(wave * kMelMaxItems + i) * 2];
+        const f32x4 acc = mel_item(tb.mel_grp[ia.x].x, ia.y, ia.z, tb.mel_coef[ia.x * 16 + f16], tb.mel_koff[ia.x * 16 + f16]);
+        mel_finish(acc, ia.x, nullptr);
+      }
+    }
+    stamp(ST_MEL);
+    if (tb.mel_n_slots > 0) {                                    // uniform for the whole grid
+      AFX_LDS_BARRIER();
+      stamp(ST_BAR3);
+      if (mel_on) {
+#pragma unroll
+        for (int i = 0; i < kMelRegItems; ++i) {
+          if (i < mel_cnt && mi_a[i].w == 2) {
+            f32x4 acc = held[i];
+            for (int sl = 0; sl < mi_b[i].y; ++sl)
+              acc += *reinterpret_cast<const f32x4*>(RB + (mi_b[i].x + sl) * 256 + lane_m * 4);
+            mel_finish(acc, mi_a[i].x, lmh[i]);
+          }
+        }
+      }
+    }
+    stamp(ST_MELFIN);
+    if (mel_on) {
+      pend = true;
+      pend_lmax = lmax; pend_slot = cur.frame_slot; pend_t0 = cur.t0; pend_T = cur.T; pend_clip = cur.clip;
     }
     // no barrier here: the next staging writes only S_ (dead since the barrier above) and PB is
     // rewritten only after the next iteration's first barrier.
     cur = nxt;
   }
+  if constexpr (STAMP) { if (lane == 0) for (int i = 0; i < ST_COUNT; ++i) stamps[((size_t)blockIdx.x * kWaves + wave) * ST_COUNT + i] = st_sum[i]; }
+  flush_logmel();
 }
 
 // ---------------------------------------------------------------------------
@@ -964,31 +1110,38 @@ hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* in
 template <int NFFT>
 static hipError_t launch_frames_t(hipStream_t s, const void* samples, ClipInfo* info,
                                   const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
-                                  float* logmel, float* rms_rows, int grid) {
+                                  float* logmel, float* rms_rows, int grid, unsigned long long* stamps) {
   const size_t lds = frames_lds_bytes(NFFT, kp.hop);
-  static bool attr_set[64] = {};
+  static bool attr_set[64][2] = {};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames<NFFT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int st = stamps ? 1 : 0;
+  if (dev >= 0 && dev < 64 && !attr_set[dev][st]) {
+    e = st ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames<NFFT, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+           : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames<NFFT, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set[dev] = true;
+    attr_set[dev][st] = true;
   }
-  hipLaunchKernelGGL(k_frames<NFFT>, dim3(grid), dim3(256), lds, s, samples, info, blocks, nblocks,
-                     tb, kp, logmel, rms_rows);
+  if (stamps)
+    hipLaunchKernelGGL((k_frames<NFFT, true>), dim3(grid), dim3(256), lds, s, samples, info, blocks, nblocks,
+                       tb, kp, logmel, rms_rows, stamps);
+  else
+    hipLaunchKernelGGL((k_frames<NFFT, false>), dim3(grid), dim3(256), lds, s, samples, info, blocks, nblocks,
+                       tb, kp, logmel, rms_rows, stamps);
   return hipGetLastError();
 }
 
 hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
                          const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
-                         float* logmel, float* rms_rows, int grid) {
+                         float* logmel, float* rms_rows, int grid, unsigned long long* stamps) {
   switch (kp.n_fft) {
-    case 256:  return launch_frames_t<256>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
-    case 512:  return launch_frames_t<512>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
-    case 1024: return launch_frames_t<1024>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
-    case 2048: return launch_frames_t<2048>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid);
+    case 256:  return launch_frames_t<256>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
+    case 512:  return launch_frames_t<512>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
+    case 1024: return launch_frames_t<1024>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
+    case 2048: return launch_frames_t<2048>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
     default: return hipErrorInvalidValue;
   }
 }

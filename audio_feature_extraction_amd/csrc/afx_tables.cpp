@@ -76,7 +76,7 @@ static void build_mel_blocks(const afx_params& p, const std::vector<float>& W,
                              const std::vector<double>& mel_f, MelBlocks& s) {
   const int M = p.n_mels, NB = p.n_fft / 2 + 1;
   const int G = (M + 15) / 16;
-  s.n_groups = G; s.grp.clear(); s.order.clear(); s.coef.clear(); s.koff.clear();
+  s.n_groups = G; s.grp.clear(); s.coef.clear(); s.koff.clear();
   const double delta = 1.0 / ((double)p.n_fft * (1.0 / (double)p.sr));
   int first_blk = 0;
   std::vector<int> nblk(G, 0);
@@ -103,21 +103,60 @@ static void build_mel_blocks(const afx_params& p, const std::vector<float>& W,
     }
     first_blk += nb;
   }
-  // balance the groups over the 4 waves: sort by block count, deal snake-wise
-  std::vector<int> idx(G);
-  for (int g = 0; g < G; ++g) idx[g] = g;
-  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return nblk[a] > nblk[b]; });
-  s.order.assign(G, 0);
-  for (int i = 0; i < G; ++i) {
-    const int r = i / 4, w = i % 4;
-    const int src = 4 * r + ((r & 1) ? 3 - w : w);
-    s.order[i] = idx[src < G ? src : i];
+  // ---- work items: split oversized groups, then longest-processing-time-first over 4 waves
+  struct Part { int g, b0, nb, role, slot, nslots; };
+  std::vector<Part> parts;
+  int total = 0;
+  for (int g = 0; g < G; ++g) total += nblk[g];
+  const double fair = std::max(1.0, total / 4.0);
+  int slots = 0;
+  for (int g = 0; g < G; ++g) {
+    if (nblk[g] == 0) { parts.push_back({g, 0, 0, 0, 0, 0}); continue; }
+    int np = 1;
+    if (nblk[g] > 0.8 * fair) np = std::min(kMelRegItems, (int)std::ceil(nblk[g] / (0.7 * fair)));
+    if (slots + (np - 1) > kMelMaxSlots) np = 1 + std::max(0, kMelMaxSlots - slots);
+    const int base = nblk[g] / np, rem = nblk[g] % np;
+    int b0 = 0;
+    for (int i = 0; i < np; ++i) {
+      const int nb = base + (i < rem ? 1 : 0);
+      Part pt{g, b0, nb, 0, 0, 0};
+      if (np > 1) {
+        if (i < np - 1) { pt.role = 1; pt.slot = slots + i; }
+        else { pt.role = 2; pt.slot = slots; pt.nslots = np - 1; }
+      }
+      parts.push_back(pt);
+      b0 += nb;
+    }
+    slots += np - 1;
   }
-  // when G is not a multiple of 4 the snake may address past the end; fall back to sorted order
-  std::vector<char> seen(G, 0);
-  bool ok = true;
-  for (int i = 0; i < G; ++i) { if (seen[s.order[i]]) ok = false; seen[s.order[i]] = 1; }
-  if (!ok) for (int i = 0; i < G; ++i) s.order[i] = idx[i];
+  s.n_slots = slots;
+  std::stable_sort(parts.begin(), parts.end(), [](const Part& a, const Part& b) { return a.nb > b.nb; });
+  int load[4] = {0, 0, 0, 0};
+  std::vector<Part> per[4];
+  for (const Part& pt : parts) {
+    int best = -1;
+    for (int w = 0; w < 4; ++w) {
+      if ((int)per[w].size() >= kMelMaxItems) continue;
+      bool clash = false;      // parts of one group go to different waves
+      for (const Part& q : per[w]) if (q.g == pt.g) clash = true;
+      if (clash) continue;
+      if (best < 0 || load[w] < load[best]) best = w;
+    }
+    if (best < 0) best = (int)(std::min_element(load, load + 4) - load);
+    per[best].push_back(pt);
+    load[best] += pt.nb + 1;
+  }
+  for (int w = 0; w < 4; ++w)          // split parts first (they are the largest anyway)
+    std::stable_sort(per[w].begin(), per[w].end(), [](const Part& a, const Part& b) { return (a.role != 0) > (b.role != 0); });
+  s.items.assign((size_t)4 * kMelMaxItems * 8, 0);
+  for (int w = 0; w < 4; ++w) {
+    s.item_cnt[w] = (int32_t)std::min<size_t>(per[w].size(), kMelMaxItems);
+    for (int i = 0; i < s.item_cnt[w]; ++i) {
+      int32_t* it = &s.items[((size_t)w * kMelMaxItems + i) * 8];
+      const Part& pt = per[w][i];
+      it[0] = pt.g; it[1] = pt.b0; it[2] = pt.nb; it[3] = pt.role; it[4] = pt.slot; it[5] = pt.nslots;
+    }
+  }
 }
 
 static void build_dct_blocks(const afx_params& p, const std::vector<float>& D, DctBlocks& d) {
