@@ -18,6 +18,8 @@
 // its 16x4 blocks are non-zero), so they run beside the VALU instead of on it.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "afx_device.h"
 
 namespace afx {
@@ -612,6 +614,12 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
     }
   };
 
+  // experiment (AFX_DEBUG_SKIP bits 0x1000 / 0x2000): start half of the workgroups ~half a block late so
+  // that co-resident workgroups sit in complementary phases (FFT = VALU+LDS, mel = matrix pipe)
+  if (((kp.flags & 0x1000) && blockIdx.x >= gridDim.x / 2) || ((kp.flags & 0x2000) && (blockIdx.x & 1))) {
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
   RawQuad pf[MAXCH];
   BlkCtx cur = resolve(fetch_desc(blockIdx.x), blockIdx.x);
   int dnext = fetch_desc(blockIdx.x + gridDim.x);
@@ -865,26 +873,26 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
     float lmax = -INFINITY;
     float* tile = logmel + cur.frame_slot * (int64_t)M;
     auto mel_item = [&](int kmin, int b0, int nb, const float4 cf, const float ko) -> f32x4 {
-      const int row0 = kmin + 4 * b0 + q4;
+      const float* p0 = PB + (kmin + 4 * b0 + q4) * kPbStride + f16;
+      const float* const pmax = PB + (NB + kPbPadRows - 1) * kPbStride + f16;    // a zero pad row
       float kf = (float)(q4 + 4 * b0) + ko;                       // k - kc of this lane's bin, exact
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       // 8 blocks (32 bins) per step: the 8 B-operand reads are issued together and two accumulators
       // alternate, so neither the LDS latency nor the MFMA dependency serialises the chain.  Blocks
       // past the item's range get zero weight (and rows past the Nyquist bin are the zero pad rows).
-      for (int bk = 0; bk < ((kp.flags & 0x1000) ? 0 : nb); bk += 8) {
+      for (int bk = 0; bk < nb; bk += 8) {
         float pb[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          int row = row0 + 4 * (bk + i);
-          row = row < NB + kPbPadRows - 1 ? row : NB + kPbPadRows - 1;
-          pb[i] = (kp.flags & 0x4000) ? 1.0f : PB[row * kPbStride + f16];
+          const float* p = p0 + i * 4 * kPbStride;
+          pb[i] = *(p < pmax ? p : pmax);
         }
+        p0 += 8 * 4 * kPbStride;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float lo = fmaf(cf.y, kf, cf.x), hi = fmaf(cf.w, kf, cf.z);
           float w = __builtin_amdgcn_fmed3f(0.f, lo, hi);           // max(0, min(lo, hi))
           w = (bk + i < nb) ? w : 0.f;                               // the next part of a split group owns those bins
-          if (kp.flags & 0x2000) w = 1.0f;
           if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc1, 0, 0, 0);
           else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc0, 0, 0, 0);
           kf += 4.0f;
@@ -946,6 +954,420 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
     }
     // no barrier here: the next staging writes only S_ (dead since the barrier above) and PB is
     // rewritten only after the next iteration's first barrier.
+    cur = nxt;
+  }
+  if constexpr (STAMP) { if (lane == 0) for (int i = 0; i < ST_COUNT; ++i) stamps[((size_t)blockIdx.x * kWaves + wave) * ST_COUNT + i] = st_sum[i]; }
+  flush_logmel();
+}
+
+// ---------------------------------------------------------------------------
+// k_frames2: the n_fft = 1024 kernel.  Differences from the generic k_frames above:
+//   * two real frames ride one 1024-point complex FFT (z = xA + i*xB): X_A[k], X_B[k] follow from
+//     Z[k] and Z[N-k] by adds only -- no split twiddles, and no third ("mirror") exchange, because the
+//     last radix-8 pass gives each lane the butterflies j and 128-j, i.e. both Z[k] and Z[N-k];
+//   * schedule 16 x 8 x 8 on one wave (16 points per lane): two LDS exchanges of 8 KB per frame pair,
+//     image XOR-swizzled a ^ ((a>>4)&15) -> every ds_write_b64 / ds_read_b64 conflict-free;
+//   * no staging pass: a lane reads its 16+16 samples straight from global memory (256-B coalesced
+//     rows, re-reads of the 75 % frame overlap are L1/L2 hits), pre-emphasis on the fly with the
+//     predecessor taken from the neighbouring lane (DPP); the next pair's loads fly under the FFT.
+// LDS: exchange images 32 KB + power-spectrum buffer 35 KB + window 4 KB + tables 3 KB = 75 KB.
+// ---------------------------------------------------------------------------
+struct Lds2 { int ex, pb, wt, t2, rb, total; };     // float offsets
+__host__ __device__ inline Lds2 lds2_layout() {
+  Lds2 L;
+  L.ex = 0;
+  L.pb = L.ex + kWaves * 1024 * 2;
+  L.wt = L.pb + round4((513 + kPbPadRows) * kPbStride);
+  L.t2 = L.wt + 1024;
+  L.rb = L.t2 + 256;
+  L.total = L.rb + kMelMaxSlots * 256;
+  return L;
+}
+size_t frames2_lds_bytes() { return (size_t)lds2_layout().total * sizeof(float); }
+
+// radix-16 DFT in registers as 4 x 4 with the W16 twiddles as constants
+__device__ __forceinline__ void dft16(float2* x) {
+  const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+  float2 t[4][4];                       // t[k1][n2]
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) {
+    float2 a = x[n2], b = x[n2 + 4], c = x[n2 + 8], d = x[n2 + 12];
+    dft4(a, b, c, d);
+    t[0][n2] = a; t[1][n2] = b; t[2][n2] = c; t[3][n2] = d;
+  }
+  // t[k1][n2] *= W16^(n2*k1)
+  auto mulw = [&](float2 v, float wr, float wi) { return make_float2(v.x * wr - v.y * wi, v.x * wi + v.y * wr); };
+  t[1][1] = mulw(t[1][1], c1, -s1);                                   // W16^1
+  t[1][2] = make_float2((t[1][2].x + t[1][2].y) * h, (t[1][2].y - t[1][2].x) * h);   // W16^2 = W8^1
+  t[1][3] = mulw(t[1][3], s1, -c1);                                   // W16^3
+  t[2][1] = make_float2((t[2][1].x + t[2][1].y) * h, (t[2][1].y - t[2][1].x) * h);   // W16^2
+  t[2][2] = mul_mi(t[2][2]);                                          // W16^4 = -i
+  t[2][3] = make_float2((t[2][3].y - t[2][3].x) * h, (-t[2][3].x - t[2][3].y) * h);  // W16^6 = W8^3
+  t[3][1] = mulw(t[3][1], s1, -c1);                                   // W16^3
+  t[3][2] = make_float2((t[3][2].y - t[3][2].x) * h, (-t[3][2].x - t[3][2].y) * h);  // W16^6
+  t[3][3] = mulw(t[3][3], -c1, s1);                                   // W16^9 = -W16^1
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    float2 a = t[k1][0], b = t[k1][1], c = t[k1][2], d = t[k1][3];
+    dft4(a, b, c, d);
+    x[k1] = a; x[k1 + 4] = b; x[k1 + 8] = c; x[k1 + 12] = d;
+  }
+}
+
+template <int FMT, bool STAMP>
+__global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ samples,
+                                                    ClipInfo* __restrict__ info,
+                                                    const BlockDesc* __restrict__ blocks, int nblocks,
+                                                    DevTables tb, KParams kp,
+                                                    float* __restrict__ logmel,
+                                                    float* __restrict__ rms_rows,
+                                                    unsigned long long* __restrict__ stamps) {
+  constexpr int N = 1024, NB = 513;
+  unsigned long long st_sum[ST_COUNT] = {}, st_prev = 0;
+  auto stamp = [&](int ph) {
+    if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ph >= 0) st_sum[ph] += t - st_prev;
+      st_prev = t;
+    }
+  };
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const Lds2 L = lds2_layout();
+  const int hop = kp.hop, M = kp.n_mels;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float2* const EX = reinterpret_cast<float2*>(smem + L.ex) + wave * 1024;
+  float* const PB = smem + L.pb;
+  float* const WT = smem + L.wt;
+  float2* const T2 = reinterpret_cast<float2*>(smem + L.t2);
+  float* const RB = smem + L.rb;
+
+  // ---- once per workgroup: tables -> LDS, per-lane twiddles -> registers
+  for (int i = tid; i < kPbPadRows * kPbStride; i += 256) PB[NB * kPbStride + i] = 0.f;
+  const float2* w1024 = reinterpret_cast<const float2*>(tb.post);      // exp(-2 pi i k / 1024), k < 512
+  auto W = [&](int m) {                                                  // W_1024^m, 0 <= m < 1024
+    const float2 v = w1024[m & 511];
+    return (m & 512) ? make_float2(-v.x, -v.y) : v;
+  };
+  for (int i = tid; i < N; i += 256) WT[i] = 0.5f * tb.window[i];       // x0.5: the A/B split then needs no 1/2
+  if (tid < 128) T2[tid] = W(8 * (tid >> 3) * (tid & 7));               // pass-2 twiddles W_128^(c*r), c = tid>>3
+  const int ja = lane, jb = lane ? 128 - lane : 64;                      // last-pass butterflies of this lane
+  float2 tw3a[7], tw3b[7];
+#pragma unroll
+  for (int r = 1; r < 8; ++r) { tw3a[r - 1] = W(ja * r); tw3b[r - 1] = W(jb * r); }
+  // exchange-image slots (see header): all per-lane bases
+  const int sA1 = 16 * lane + (lane & 15);
+  const int sR1 = lane ^ (lane >> 4);
+  const int sW2a = 128 * (lane >> 4) + ((lane & 15) ^ (((lane >> 4) & 1) << 3));
+  const int sW2b = sW2a + 512;                                           // butterfly j = lane + 64: x = (lane>>4) + 4, same parity
+  const int sRa = ja ^ ((ja >> 4) & 7), sRb = jb ^ ((jb >> 4) & 7);
+
+  // mel work items of this wave (see k_frames)
+  const int mel_cnt = __builtin_amdgcn_readfirstlane(
+      tb.mel_item_cnt[0] * (wave == 0) + tb.mel_item_cnt[1] * (wave == 1) +
+      tb.mel_item_cnt[2] * (wave == 2) + tb.mel_item_cnt[3] * (wave == 3));
+  int4 mi_a[kMelRegItems], mi_b[kMelRegItems];
+  float4 mi_cf[kMelRegItems];
+  float mi_ko[kMelRegItems];
+#pragma unroll
+  for (int i = 0; i < kMelRegItems; ++i) {
+    mi_a[i] = make_int4(0, 0, 0, 0); mi_b[i] = make_int4(0, 0, 0, 0);
+    mi_cf[i] = make_float4(0.f, 0.f, 0.f, 0.f); mi_ko[i] = 0.f;
+    if (i < mel_cnt) {
+      auto sg = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+      const int4 a = tb.mel_items[(wave * kMelMaxItems + i) * 2], bb = tb.mel_items[(wave * kMelMaxItems + i) * 2 + 1];
+      mi_a[i] = make_int4(sg(a.x), sg(a.y), sg(a.z), sg(a.w));
+      mi_b[i] = make_int4(sg(bb.x), sg(bb.y), sg(tb.mel_grp[a.x].x), 0);
+      mi_cf[i] = tb.mel_coef[mi_a[i].x * 16 + (lane & 15)];
+      mi_ko[i] = tb.mel_koff[mi_a[i].x * 16 + (lane & 15)];
+    }
+  }
+  const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
+  const float b1 = kp.preemph_b1;
+
+  auto fetch_desc = [&](int b) -> int {
+    const int bb = b < nblocks ? b : nblocks - 1;
+    return reinterpret_cast<const int*>(blocks + bb)[lane & 15];
+  };
+  auto resolve = [&](int w, int b) -> BlkCtx {
+    BlkCtx c;
+    auto rl = [&](int i) { return __builtin_amdgcn_readlane(w, i); };
+    auto rl64 = [&](int i) { return (int64_t)(((uint64_t)(uint32_t)rl(i + 1) << 32) | (uint32_t)rl(i)); };
+    c.sample_base = rl64(0); c.frame_slot = rl64(2); c.clip_off = rl64(4);
+    c.keep_lo = rl(6); c.keep_hi = rl(7); c.have_lo = rl(8); c.have_hi = rl(9);
+    c.clip = rl(10); c.t0 = rl(11); c.T = rl(12);
+    c.active = (b < nblocks) && rl(13) != 0;
+    c.interior = false;
+    return c;
+  };
+
+  // deferred log-mel stores (see k_frames)
+  float lmh[kMelRegItems][4];
+  bool pend = false;
+  float pend_lmax = -INFINITY;
+  int64_t pend_slot = 0;
+  int pend_t0 = 0, pend_T = 0, pend_clip = 0;
+  auto flush_logmel = [&]() {
+    if (!pend) return;
+    pend = false;
+    int lane_f = lane;
+    asm volatile("" : "+v"(lane_f));
+    const int f16 = lane_f & 15, q4 = lane_f >> 4;
+    const bool valid = (pend_t0 + f16) < pend_T;
+    float* tile = logmel + pend_slot * (int64_t)M;
+#pragma unroll
+    for (int i = 0; i < kMelRegItems; ++i) {
+      if (i < mel_cnt && mi_a[i].w != 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = mi_a[i].x * 16 + q4 * 4 + r;
+          if (valid && m < M) tile[m * 16 + f16] = lmh[i][r];
+        }
+      }
+    }
+    const float mx = wave_max(pend_lmax);
+    if (lane_f == 0 && mx > -INFINITY) atomicMax(&info[pend_clip].lmax_ord, f2ord(mx));
+  };
+
+  // ---- sample fetch: raw values of the NEXT pair live in registers while the current pair transforms
+  float nxa[16], nxb[16], npa = 0.f, npb = 0.f;
+  bool nfast = false;
+  auto raw_ld = [&](int64_t idx) -> float {            // bit pattern of one sample (converted at use)
+    if constexpr (FMT == AFX_FMT_S16) return __int_as_float((int)((const int16_t*)samples)[idx]);
+    else return ((const float*)samples)[idx];
+  };
+  auto cvt = [&](float raw) -> float {
+    if constexpr (FMT == AFX_FMT_S16) return (float)__float_as_int(raw) * (1.0f / 32768.0f);
+    else return raw;
+  };
+  auto pair_is_interior = [&](const BlkCtx& c, int fl) -> bool {       // both frames: all samples and their
+    const int j0 = fl * hop, j1 = j0 + hop + N;                        // predecessors exist and are kept
+    return (j0 - 1 >= c.have_lo) && (j1 <= c.have_hi) && (j0 >= c.keep_lo) && (j1 <= c.keep_hi);
+  };
+  auto issue_pair = [&](const BlkCtx& c, int fl) {
+    nfast = c.active && pair_is_interior(c, fl);
+    if (nfast) {
+      const int64_t ba = c.sample_base + (int64_t)fl * hop + lane;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { nxa[u] = raw_ld(ba + 64 * u); nxb[u] = raw_ld(ba + hop + 64 * u); }
+      npa = raw_ld(c.sample_base + (int64_t)fl * hop - 1);             // wave-uniform address
+      npb = raw_ld(c.sample_base + (int64_t)fl * hop + hop - 1);
+    }
+  };
+  auto edge_sample = [&](const BlkCtx& c, int j) -> float {            // pre-emphasised, trim-masked sample j
+    const int lo = c.have_lo, hi = c.have_hi - 1;
+    const int jc = j < lo ? lo : (j > hi ? hi : j), jp = (j - 1) < lo ? lo : ((j - 1) > hi ? hi : (j - 1));
+    const float y = (jc == j) ? cvt(raw_ld(c.sample_base + jc)) : 0.f;
+    const float yp = (jp == j - 1) ? cvt(raw_ld(c.sample_base + jp)) : 0.f;
+    float v = y;
+    if (pre) {
+      v = preemph1(y, yp, b1);
+      if (j == lo) v = preemph0(cvt(raw_ld(c.clip_off)), cvt(raw_ld(c.clip_off + 1)));   // clip sample 0
+    }
+    return (j >= c.keep_lo && j < c.keep_hi) ? v : 0.f;
+  };
+
+  BlkCtx cur = resolve(fetch_desc(blockIdx.x), blockIdx.x);
+  int dnext = fetch_desc(blockIdx.x + gridDim.x);
+  issue_pair(cur, wave * 4);
+  AFX_LDS_BARRIER();
+
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    stamp(-1);
+    const BlkCtx nxt = resolve(dnext, b + gridDim.x);
+    dnext = fetch_desc(b + 2 * gridDim.x);
+
+    if (cur.active && !(kp.flags & 0x200)) {
+#pragma unroll 1
+      for (int pr = 0; pr < 2; ++pr) {
+        const int flA = wave * 4 + 2 * pr;
+        // ---- consume the fetched pair: pre-emphasis, RMS, window -> z = wA*yA + i*wB*yB
+        float2 v[16];
+        float ssA = 0.f, ssB = 0.f;
+        if (nfast) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const float xa = cvt(nxa[u]), xb = cvt(nxb[u]);
+            float ya = xa, yb = xb;
+            if (pre) {
+              // predecessor = previous lane's sample (wave_shr:1); lane 0 takes lane 63 of the row above
+              // (wave_ror:1 of u-1) or, for u = 0, the sample before the frame
+              const float oa = (u == 0) ? cvt(npa) : AFX_DPP(cvt(nxa[u > 0 ? u - 1 : 0]), 0x13C);
+              const float ob = (u == 0) ? cvt(npb) : AFX_DPP(cvt(nxb[u > 0 ? u - 1 : 0]), 0x13C);
+              const float pa = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(oa), __float_as_int(xa), 0x138, 0xf, 0xf, false));
+              const float pb = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ob), __float_as_int(xb), 0x138, 0xf, 0xf, false));
+              ya = preemph1(xa, pa, b1); yb = preemph1(xb, pb, b1);
+            }
+            ssA += ya * ya; ssB += yb * yb;
+            const float w = WT[lane + 64 * u];
+            v[u] = make_float2(w * ya, w * yb);
+          }
+        } else {
+          const int jA = flA * hop + lane;
+#pragma unroll                    // (full unroll: v[] must keep compile-time indices to stay in registers)
+          for (int u = 0; u < 16; ++u) {
+            const float ya = edge_sample(cur, jA + 64 * u), yb = edge_sample(cur, jA + hop + 64 * u);
+            ssA += ya * ya; ssB += yb * yb;
+            const float w = WT[lane + 64 * u];
+            v[u] = make_float2(w * ya, w * yb);
+          }
+        }
+        ssA = wave_sum(ssA); ssB = wave_sum(ssB);
+        if (lane == 0) {
+          if (cur.t0 + flA < cur.T) rms_rows[cur.frame_slot + flA] = sqrtf(ssA / (float)N);
+          if (cur.t0 + flA + 1 < cur.T) rms_rows[cur.frame_slot + flA + 1] = sqrtf(ssB / (float)N);
+        }
+        if (pr == 0) flush_logmel();        // older than every load issued from here on
+        // ---- fetch the next pair (this block's second pair, or the next block's first)
+        if (pr == 0) issue_pair(cur, flA + 2); else issue_pair(nxt, wave * 4);
+
+        // ---- pass 1: radix 16 (no twiddles), exchange
+        dft16(v);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) EX[sA1 ^ r] = v[r];
+        AFX_CBARRIER();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = EX[(sR1 ^ ((u & 3) << 2)) + 64 * u];
+        AFX_CBARRIER();
+        // ---- pass 2: radix 8 x 2 butterflies (j = lane, lane + 64): inputs u = i + 2r, twiddle W_128^((lane&15) r)
+        {
+          float2 t2v[8];
+#pragma unroll
+          for (int r = 1; r < 8; ++r) t2v[r] = T2[(lane & 15) * 8 + r];
+          float2 xa[8], xb[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) { xa[r] = v[2 * r]; xb[r] = v[2 * r + 1]; }
+#pragma unroll
+          for (int r = 1; r < 8; ++r) { xa[r] = cmul(xa[r], t2v[r]); xb[r] = cmul(xb[r], t2v[r]); }
+          dft<8>(xa); dft<8>(xb);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) { EX[sW2a ^ (17 * r)] = xa[r]; EX[sW2b ^ (17 * r)] = xb[r]; }
+        }
+        AFX_CBARRIER();
+        // ---- pass 3: radix 8, butterflies ja = lane and jb = 128 - lane (lane 0: 0 and 64)
+        float2 A[8], B[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          A[r] = EX[(sRa ^ ((r & 1) << 3)) + 128 * r];
+          B[r] = EX[(sRb ^ ((r & 1) << 3)) + 128 * r];
+        }
+        AFX_CBARRIER();
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { A[r] = cmul(A[r], tw3a[r - 1]); B[r] = cmul(B[r], tw3b[r - 1]); }
+        dft<8>(A); dft<8>(B);
+        // ---- A[r] = Z[lane + 128 r], B[r] = Z[128 - lane + 128 r]: pair s holds Z[k], Z[N-k] with
+        // k = lane + 128 s.  Lane 0 owns the self-mirrored butterflies 0 and 64 and pairs inside them.
+        const bool l0 = lane == 0;
+        float* const pcol = PB + flA;
+        auto power = [&](float2 za, float2 zb, int bin) {
+          const float ar = za.x + zb.x, ai = za.y - zb.y, br = za.y + zb.y, bi = za.x - zb.x;
+          pcol[bin * kPbStride] = ar * ar + ai * ai;           // |X_A[bin]|^2
+          pcol[bin * kPbStride + 1] = br * br + bi * bi;       // |X_B[bin]|^2
+        };
+        auto sel = [&](float2 a, float2 b) { return make_float2(l0 ? b.x : a.x, l0 ? b.y : a.y); };
+        power(sel(A[0], A[1]), sel(B[7], A[7]), l0 ? 128 : lane);
+        power(sel(A[1], A[2]), sel(B[6], A[6]), l0 ? 256 : lane + 128);
+        power(sel(A[2], A[3]), sel(B[5], A[5]), l0 ? 384 : lane + 256);
+        power(sel(A[3], B[0]), sel(B[4], B[7]), l0 ? 64 : lane + 384);
+        power(sel(A[4], B[1]), sel(B[3], B[6]), l0 ? 192 : 512 - lane);
+        power(sel(A[5], B[2]), sel(B[2], B[5]), l0 ? 320 : 384 - lane);
+        power(sel(A[6], B[3]), sel(B[1], B[4]), l0 ? 448 : 256 - lane);
+        power(sel(A[7], A[0]), sel(B[0], A[0]), l0 ? 0 : 128 - lane);
+        if (l0) {                                              // Nyquist bin from Z[512] = A[4]
+          pcol[512 * kPbStride] = 4.f * A[4].x * A[4].x;
+          pcol[512 * kPbStride + 1] = 4.f * A[4].y * A[4].y;
+        }
+        AFX_CBARRIER();
+      }
+    } else {
+      flush_logmel();
+      issue_pair(nxt, wave * 4);
+    }
+    stamp(ST_FFT);
+    AFX_LDS_BARRIER();
+    stamp(ST_BAR2);
+
+    // ---- mel filterbank + dB on the matrix pipe (as k_frames)
+    const bool mel_on = cur.active && !(kp.flags & 0x400);
+    int lane_m = lane;
+    asm volatile("" : "+v"(lane_m));
+    const int f16 = lane_m & 15, q4 = lane_m >> 4;
+    const bool valid = (cur.t0 + f16) < cur.T;
+    float lmax = -INFINITY;
+    float* tile = logmel + cur.frame_slot * (int64_t)M;
+    auto mel_item = [&](int kmin, int b0, int nb, const float4 cf, const float ko) -> f32x4 {
+      const float* p0 = PB + (kmin + 4 * b0 + q4) * kPbStride + f16;
+      const float* const pmax = PB + (NB + kPbPadRows - 1) * kPbStride + f16;
+      float kf = (float)(q4 + 4 * b0) + ko;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      for (int bk = 0; bk < nb; bk += 8) {
+        float pb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float* p = p0 + i * 4 * kPbStride;
+          pb[i] = *(p < pmax ? p : pmax);
+        }
+        p0 += 8 * 4 * kPbStride;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float lo = fmaf(cf.y, kf, cf.x), hi = fmaf(cf.w, kf, cf.z);
+          float w = __builtin_amdgcn_fmed3f(0.f, lo, hi);
+          w = (bk + i < nb) ? w : 0.f;
+          if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc1, 0, 0, 0);
+          else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc0, 0, 0, 0);
+          kf += 4.0f;
+        }
+      }
+      return acc0 + acc1;
+    };
+    auto mel_finish = [&](const f32x4 acc, int g, float* dst) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = g * 16 + q4 * 4 + r;
+        const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc[r]));
+        if (dst) dst[r] = Lv;
+        if (valid && m < M) {
+          if (!dst && !(kp.flags & 0x800)) tile[m * 16 + f16] = Lv;
+          lmax = fmaxf(lmax, Lv);
+        }
+      }
+    };
+    f32x4 held[kMelRegItems];
+    if (mel_on) {
+#pragma unroll
+      for (int i = 0; i < kMelRegItems; ++i) {
+        if (i < mel_cnt) {
+          held[i] = mel_item(mi_b[i].z, mi_a[i].y, mi_a[i].z, mi_cf[i], mi_ko[i]);
+          if (mi_a[i].w == 0) mel_finish(held[i], mi_a[i].x, lmh[i]);
+          else if (mi_a[i].w == 1) *reinterpret_cast<f32x4*>(RB + mi_b[i].x * 256 + lane_m * 4) = held[i];
+        }
+      }
+      for (int i = kMelRegItems; i < mel_cnt; ++i) {
+        const int4 ia = tb.mel_items[(wave * kMelMaxItems + i) * 2];
+        const f32x4 acc = mel_item(tb.mel_grp[ia.x].x, ia.y, ia.z, tb.mel_coef[ia.x * 16 + f16], tb.mel_koff[ia.x * 16 + f16]);
+        mel_finish(acc, ia.x, nullptr);
+      }
+    }
+    stamp(ST_MEL);
+    AFX_LDS_BARRIER();      // PB is free for the next block's spectra; split groups' partial sums are in RB
+    stamp(ST_BAR3);
+    if (mel_on) {
+#pragma unroll
+      for (int i = 0; i < kMelRegItems; ++i) {
+        if (i < mel_cnt && mi_a[i].w == 2) {
+          f32x4 acc = held[i];
+          for (int sl = 0; sl < mi_b[i].y; ++sl)
+            acc += *reinterpret_cast<const f32x4*>(RB + (mi_b[i].x + sl) * 256 + lane_m * 4);
+          mel_finish(acc, mi_a[i].x, lmh[i]);
+        }
+      }
+      pend = true;
+      pend_lmax = lmax; pend_slot = cur.frame_slot; pend_t0 = cur.t0; pend_T = cur.T; pend_clip = cur.clip;
+    }
+    stamp(ST_MELFIN);
     cur = nxt;
   }
   if constexpr (STAMP) { if (lane == 0) for (int i = 0; i < ST_COUNT; ++i) stamps[((size_t)blockIdx.x * kWaves + wave) * ST_COUNT + i] = st_sum[i]; }
@@ -1134,9 +1556,35 @@ static hipError_t launch_frames_t(hipStream_t s, const void* samples, ClipInfo* 
   return hipGetLastError();
 }
 
+template <int FMT, bool STAMP>
+static hipError_t launch_frames2_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
+                                   int nblocks, const DevTables& tb, const KParams& kp, float* logmel,
+                                   float* rms_rows, int grid, unsigned long long* stamps) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames2<FMT, STAMP>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((k_frames2<FMT, STAMP>), dim3(grid), dim3(256), frames2_lds_bytes(), s, samples, info, blocks,
+                     nblocks, tb, kp, logmel, rms_rows, stamps);
+  return hipGetLastError();
+}
+
 hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
                          const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
                          float* logmel, float* rms_rows, int grid, unsigned long long* stamps) {
+  if (kp.n_fft == 1024 && !getenv("AFX_GENERIC_1024")) {
+    if (kp.fmt == AFX_FMT_S16)
+      return stamps ? launch_frames2_t<AFX_FMT_S16, true>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps)
+                    : launch_frames2_t<AFX_FMT_S16, false>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
+    return stamps ? launch_frames2_t<AFX_FMT_F32, true>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps)
+                  : launch_frames2_t<AFX_FMT_F32, false>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
+  }
   switch (kp.n_fft) {
     case 256:  return launch_frames_t<256>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
     case 512:  return launch_frames_t<512>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
