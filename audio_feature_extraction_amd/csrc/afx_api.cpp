@@ -363,7 +363,7 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
       std::vector<unsigned long long> h((size_t)grid * kWaves * kStampPhases);
       HIP_TRY(hipMemcpyAsync(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
-      static const char* names[kStampPhases] = {"stage", "bar1", "fft", "prefetch", "bar2", "mel", "bar3", "melfin"};
+      static const char* names[kStampPhases] = {"stage", "bar1", "fft", "prefetch", "bar2", "mel", "bar3", "melfin", "x0", "x1", "x2", "x3"};
       double tot[kStampPhases] = {}, wv[kWaves][kStampPhases] = {};
       for (int g = 0; g < grid; ++g)
         for (int w = 0; w < kWaves; ++w)

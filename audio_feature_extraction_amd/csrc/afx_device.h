@@ -81,7 +81,7 @@ hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* in
 hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
                          const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
                          float* logmel, float* rms_rows, int grid, unsigned long long* stamps = nullptr);
-constexpr int kStampPhases = 8;
+constexpr int kStampPhases = 12;
 hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
                       const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax);
 hipError_t launch_stats(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const KParams& kp,

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "afx_device.h"
 
@@ -459,7 +460,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // STAMP = true is a separate diagnostic instantiation (AFX_DEBUG_STAMPS): lane 0 of every wave sums
 // s_memtime deltas per phase into `stamps`; the production kernel carries none of it.
-enum { ST_STAGE = 0, ST_BAR1, ST_FFT, ST_PREFETCH, ST_BAR2, ST_MEL, ST_BAR3, ST_MELFIN, ST_COUNT };
+enum { ST_STAGE = 0, ST_BAR1, ST_FFT, ST_PREFETCH, ST_BAR2, ST_MEL, ST_BAR3, ST_MELFIN, ST_X0, ST_X1, ST_X2, ST_X3, ST_COUNT };
 
 template <int NFFT, bool STAMP>
 __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const void* __restrict__ samples,
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
       // window pre-scaled by 1/2 (exact): the split below then yields X, not 2X, and |X|^2 needs no 0.25
       for (int i = tid; i < N2; i += 256) { WT[i] = make_float2(0.5f * w2[i].x, 0.5f * w2[i].y); PT[i] = p2[i]; }
       // pass-2 twiddles W_64^(c*r), c = lane & 7: 64 values, read per frame pair instead of 14 registers per lane
-      if (tid < 64) T2[tid] = reinterpret_cast<const float2*>(tb.tw)[(tid >> 3) * (tid & 7) * (N2 / 64)];
+      if (tid < 64) T2[tid] = reinterpret_cast<const float2*>(tb.tw)[(tid >> 3) * (tid & 7) * (N2 / 64)];   // [r*8 + c], symmetric in (r, c)
     }
     if constexpr (!FAST) {
 #pragma unroll
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
           // pass 2
           float2 t2v[8];
 #pragma unroll
-          for (int r = 1; r < 8; ++r) t2v[r] = T2[(lane & 7) * 8 + r];
+          for (int r = 1; r < 8; ++r) t2v[r] = T2[r * 8 + (lane & 7)];
 #pragma unroll
           for (int r = 1; r < 8; ++r) vA[r] = cmul(vA[r], t2v[r]);
           dft<8>(vA);
@@ -972,7 +973,7 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
 //     predecessor taken from the neighbouring lane (DPP); the next pair's loads fly under the FFT.
 // LDS: exchange images 32 KB + power-spectrum buffer 35 KB + window 4 KB + tables 3 KB = 75 KB.
 // ---------------------------------------------------------------------------
-struct Lds2 { int ex, pb, wt, t2, rb, total; };     // float offsets
+struct Lds2 { int ex, pb, wt, t2, rb, t3, mc, total; };     // float offsets
 __host__ __device__ inline Lds2 lds2_layout() {
   Lds2 L;
   L.ex = 0;
@@ -980,7 +981,9 @@ __host__ __device__ inline Lds2 lds2_layout() {
   L.wt = L.pb + round4((513 + kPbPadRows) * kPbStride);
   L.t2 = L.wt + 1024;
   L.rb = L.t2 + 256;
-  L.total = L.rb + kMelMaxSlots * 256;
+  L.t3 = L.rb + kMelMaxSlots * 256;        // last-pass twiddles of butterfly jb: 7 x 64 float2
+  L.mc = L.t3 + 7 * 64 * 2;                // mel triangle coefficients: 8 groups x 16 rows x (float4 + float)
+  L.total = L.mc + 8 * 16 * 5;
   return L;
 }
 size_t frames2_lds_bytes() { return (size_t)lds2_layout().total * sizeof(float); }
@@ -1044,6 +1047,9 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   float* const WT = smem + L.wt;
   float2* const T2 = reinterpret_cast<float2*>(smem + L.t2);
   float* const RB = smem + L.rb;
+  float2* const T3 = reinterpret_cast<float2*>(smem + L.t3);
+  float4* const MC4 = reinterpret_cast<float4*>(smem + L.mc);
+  float* const MCK = smem + L.mc + 8 * 16 * 4;
 
   // ---- once per workgroup: tables -> LDS, per-lane twiddles -> registers
   for (int i = tid; i < kPbPadRows * kPbStride; i += 256) PB[NB * kPbStride + i] = 0.f;
@@ -1053,11 +1059,18 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     return (m & 512) ? make_float2(-v.x, -v.y) : v;
   };
   for (int i = tid; i < N; i += 256) WT[i] = 0.5f * tb.window[i];       // x0.5: the A/B split then needs no 1/2
-  if (tid < 128) T2[tid] = W(8 * (tid >> 3) * (tid & 7));               // pass-2 twiddles W_128^(c*r), c = tid>>3
+  if (tid < 128) T2[tid] = W(8 * (tid >> 4) * (tid & 15));              // pass-2 twiddles W_128^(c*r) at [r*16 + c]: a row per r,
+                                                                         // so the 16 distinct c of a wave read 128 contiguous bytes
   const int ja = lane, jb = lane ? 128 - lane : 64;                      // last-pass butterflies of this lane
-  float2 tw3a[7], tw3b[7];
+  float2 tw3a[7];                                                        // butterfly ja: registers; jb: LDS table
 #pragma unroll
-  for (int r = 1; r < 8; ++r) { tw3a[r - 1] = W(ja * r); tw3b[r - 1] = W(jb * r); }
+  for (int r = 1; r < 8; ++r) tw3a[r - 1] = W(ja * r);
+  if (tid < 64) {
+#pragma unroll
+    for (int r = 1; r < 8; ++r) T3[(r - 1) * 64 + tid] = W(jb * r);
+  }
+  const bool mel_lds = tb.n_groups <= 8;                                 // coefficient table fits its LDS slot
+  if (mel_lds && tid < tb.n_groups * 16) { MC4[tid] = tb.mel_coef[tid]; MCK[tid] = tb.mel_koff[tid]; }
   // exchange-image slots (see header): all per-lane bases
   const int sA1 = 16 * lane + (lane & 15);
   const int sR1 = lane ^ (lane >> 4);
@@ -1070,19 +1083,14 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
       tb.mel_item_cnt[0] * (wave == 0) + tb.mel_item_cnt[1] * (wave == 1) +
       tb.mel_item_cnt[2] * (wave == 2) + tb.mel_item_cnt[3] * (wave == 3));
   int4 mi_a[kMelRegItems], mi_b[kMelRegItems];
-  float4 mi_cf[kMelRegItems];
-  float mi_ko[kMelRegItems];
 #pragma unroll
   for (int i = 0; i < kMelRegItems; ++i) {
     mi_a[i] = make_int4(0, 0, 0, 0); mi_b[i] = make_int4(0, 0, 0, 0);
-    mi_cf[i] = make_float4(0.f, 0.f, 0.f, 0.f); mi_ko[i] = 0.f;
     if (i < mel_cnt) {
       auto sg = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
       const int4 a = tb.mel_items[(wave * kMelMaxItems + i) * 2], bb = tb.mel_items[(wave * kMelMaxItems + i) * 2 + 1];
       mi_a[i] = make_int4(sg(a.x), sg(a.y), sg(a.z), sg(a.w));
       mi_b[i] = make_int4(sg(bb.x), sg(bb.y), sg(tb.mel_grp[a.x].x), 0);
-      mi_cf[i] = tb.mel_coef[mi_a[i].x * 16 + (lane & 15)];
-      mi_ko[i] = tb.mel_koff[mi_a[i].x * 16 + (lane & 15)];
     }
   }
   const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
@@ -1132,9 +1140,13 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     if (lane_f == 0 && mx > -INFINITY) atomicMax(&info[pend_clip].lmax_ord, f2ord(mx));
   };
 
-  // ---- sample fetch: raw values of the NEXT pair live in registers while the current pair transforms
-  float nxa[16], nxb[16], npa = 0.f, npb = 0.f;
-  bool nfast = false;
+  // ---- sample rows.  A lane holds samples l + 64u ("row" u).  hop = 256 = 4 rows, so frame B of a pair is
+  // frame A shifted by 4 rows and the wave's second pair starts 8 rows after the first: one window of
+  // 20 rows serves pair 0, 12 of them plus 8 new rows serve pair 1.  Rows are fetched raw (next block's
+  // 20 rows under the second pair's FFT and the mel phase; the 8 new rows under the first pair's FFT),
+  // pre-emphasised once in place, and shared by the two frames of a pair.
+  float rows[20], inc[8], np_rows = 0.f, np_inc = 0.f;
+  bool rows_raw = false, inc_raw = false;              // false: the pair is an edge pair (clamped path)
   auto raw_ld = [&](int64_t idx) -> float {            // bit pattern of one sample (converted at use)
     if constexpr (FMT == AFX_FMT_S16) return __int_as_float((int)((const int16_t*)samples)[idx]);
     else return ((const float*)samples)[idx];
@@ -1147,15 +1159,41 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     const int j0 = fl * hop, j1 = j0 + hop + N;                        // predecessors exist and are kept
     return (j0 - 1 >= c.have_lo) && (j1 <= c.have_hi) && (j0 >= c.keep_lo) && (j1 <= c.keep_hi);
   };
-  auto issue_pair = [&](const BlkCtx& c, int fl) {
-    nfast = c.active && pair_is_interior(c, fl);
-    if (nfast) {
-      const int64_t ba = c.sample_base + (int64_t)fl * hop + lane;
+  auto issue_rows = [&](const BlkCtx& c) {             // first pair of block c: rows 0..19
+    rows_raw = c.active && pair_is_interior(c, wave * 4);
+    if (rows_raw && !(kp.flags & 0x100)) {             // 0x100: timing-only ablation (stale registers)
+      const int64_t ba = c.sample_base + (int64_t)(wave * 4) * hop;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { nxa[u] = raw_ld(ba + 64 * u); nxb[u] = raw_ld(ba + hop + 64 * u); }
-      npa = raw_ld(c.sample_base + (int64_t)fl * hop - 1);             // wave-uniform address
-      npb = raw_ld(c.sample_base + (int64_t)fl * hop + hop - 1);
+      for (int u = 0; u < 20; ++u) rows[u] = raw_ld(ba + lane + 64 * u);
+      np_rows = raw_ld(ba - 1);                        // wave-uniform address
     }
+  };
+  auto issue_inc = [&](const BlkCtx& c) {              // second pair: its 8 new rows (20..27 of the window)
+    inc_raw = pair_is_interior(c, wave * 4 + 2);
+    if (inc_raw && !(kp.flags & 0x100)) {
+      const int64_t ba = c.sample_base + (int64_t)(wave * 4) * hop + 64 * 20;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) inc[u] = raw_ld(ba + lane + 64 * u);
+      np_inc = raw_ld(ba - 1);
+    }
+  };
+  // In-place pre-emphasis of NR consecutive raw rows (p0 = the sample before the first row's lane 0).
+  // The left neighbour of a sample sits in the neighbouring lane, or across a row seam; rather than
+  // chasing it with cross-lane moves, the rows take a trip through this wave's (idle) exchange image:
+  // written at offset 1, read back at offset 0 -- both conflict-free ds_*_b32 rows.
+  float* const XB = reinterpret_cast<float*>(EX);
+  auto preemph_rows = [&](float* r, float p0, auto NRt) {
+    constexpr int NR = decltype(NRt)::value;
+#pragma unroll
+    for (int u = 0; u < NR; ++u) { r[u] = cvt(r[u]); XB[1 + 64 * u + lane] = r[u]; }
+    XB[0] = cvt(p0);
+    AFX_CBARRIER();
+    float prev[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) prev[u] = XB[64 * u + lane];
+    AFX_CBARRIER();
+#pragma unroll
+    for (int u = 0; u < NR; ++u) r[u] = preemph1(r[u], prev[u], b1);
   };
   auto edge_sample = [&](const BlkCtx& c, int j) -> float {            // pre-emphasised, trim-masked sample j
     const int lo = c.have_lo, hi = c.have_hi - 1;
@@ -1170,9 +1208,89 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     return (j >= c.keep_lo && j < c.keep_hi) ? v : 0.f;
   };
 
+  // ---- one pair: z = w*yA + i*w*yB -> 1024-point FFT -> |X_A|^2, |X_B|^2 into PB columns flA, flA+1
+  auto fft_pair = [&](float2 (&v)[16], int flA) {
+    stamp(ST_STAGE);
+    // pass 1: radix 16 (no twiddles), exchange
+    dft16(v);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) EX[sA1 ^ r] = v[r];
+    AFX_CBARRIER();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = EX[(sR1 ^ ((u & 3) << 2)) + 64 * u];
+    AFX_CBARRIER();
+    stamp(ST_BAR1);
+    // pass 2: radix 8 x 2 butterflies (j = lane, lane + 64): inputs u = i + 2r, twiddle W_128^((lane&15) r)
+    {
+      float2 t2v[8];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) t2v[r] = T2[r * 16 + (lane & 15)];
+      float2 xa[8], xb[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { xa[r] = v[2 * r]; xb[r] = v[2 * r + 1]; }
+#pragma unroll
+      for (int r = 1; r < 8; ++r) { xa[r] = cmul(xa[r], t2v[r]); xb[r] = cmul(xb[r], t2v[r]); }
+      dft<8>(xa); dft<8>(xb);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { EX[sW2a ^ (17 * r)] = xa[r]; EX[sW2b ^ (17 * r)] = xb[r]; }
+    }
+    AFX_CBARRIER();
+    stamp(ST_PREFETCH);
+    // pass 3: radix 8, butterflies ja = lane and jb = 128 - lane (lane 0: 0 and 64)
+    float2 A[8], B[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      A[r] = EX[(sRa ^ ((r & 1) << 3)) + 128 * r];
+      B[r] = EX[(sRb ^ ((r & 1) << 3)) + 128 * r];
+    }
+    AFX_CBARRIER();
+#pragma unroll
+    for (int r = 1; r < 8; ++r) { A[r] = cmul(A[r], tw3a[r - 1]); B[r] = cmul(B[r], T3[(r - 1) * 64 + lane]); }
+    dft<8>(A); dft<8>(B);
+    // A[r] = Z[lane + 128 r], B[r] = Z[128 - lane + 128 r]: pair s holds Z[k], Z[N-k] with k = lane + 128 s.
+    // Lane 0 owns the self-mirrored butterflies 0 and 64 and pairs inside them.
+    const bool l0 = lane == 0;
+    float* const pcol = PB + flA;
+    auto power = [&](float2 za, float2 zb, int bin) {
+      const float ar = za.x + zb.x, ai = za.y - zb.y, br = za.y + zb.y, bi = za.x - zb.x;
+      pcol[bin * kPbStride] = ar * ar + ai * ai;           // |X_A[bin]|^2
+      pcol[bin * kPbStride + 1] = br * br + bi * bi;       // |X_B[bin]|^2
+    };
+    auto sel = [&](float2 a, float2 b) { return make_float2(l0 ? b.x : a.x, l0 ? b.y : a.y); };
+    power(sel(A[0], A[1]), sel(B[7], A[7]), l0 ? 128 : lane);
+    power(sel(A[1], A[2]), sel(B[6], A[6]), l0 ? 256 : lane + 128);
+    power(sel(A[2], A[3]), sel(B[5], A[5]), l0 ? 384 : lane + 256);
+    power(sel(A[3], B[0]), sel(B[4], B[7]), l0 ? 64 : lane + 384);
+    power(sel(A[4], B[1]), sel(B[3], B[6]), l0 ? 192 : 512 - lane);
+    power(sel(A[5], B[2]), sel(B[2], B[5]), l0 ? 320 : 384 - lane);
+    power(sel(A[6], B[3]), sel(B[1], B[4]), l0 ? 448 : 256 - lane);
+    power(sel(A[7], A[0]), sel(B[0], A[0]), l0 ? 0 : 128 - lane);
+    if (l0) {                                              // Nyquist bin from Z[512] = A[4]
+      pcol[512 * kPbStride] = 4.f * A[4].x * A[4].x;
+      pcol[512 * kPbStride + 1] = 4.f * A[4].y * A[4].y;
+    }
+    AFX_CBARRIER();
+    stamp(ST_FFT);
+  };
+  // window + RMS of the pair whose frame A is rows y[0..15] and frame B rows y[4..19]
+  auto make_z = [&](const float (&y)[20], float2 (&v)[16], const BlkCtx& c, int flA) {
+    float ssA = 0.f, ssB = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      ssA += y[u] * y[u]; ssB += y[u + 4] * y[u + 4];
+      const float w = WT[lane + 64 * u];
+      v[u] = make_float2(w * y[u], w * y[u + 4]);
+    }
+    ssA = wave_sum(ssA); ssB = wave_sum(ssB);
+    if (lane == 0) {
+      if (c.t0 + flA < c.T) rms_rows[c.frame_slot + flA] = sqrtf(ssA / (float)N);
+      if (c.t0 + flA + 1 < c.T) rms_rows[c.frame_slot + flA + 1] = sqrtf(ssB / (float)N);
+    }
+  };
+
   BlkCtx cur = resolve(fetch_desc(blockIdx.x), blockIdx.x);
   int dnext = fetch_desc(blockIdx.x + gridDim.x);
-  issue_pair(cur, wave * 4);
+  issue_rows(cur);
   AFX_LDS_BARRIER();
 
   for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
@@ -1181,110 +1299,62 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     dnext = fetch_desc(b + 2 * gridDim.x);
 
     if (cur.active && !(kp.flags & 0x200)) {
-#pragma unroll 1
-      for (int pr = 0; pr < 2; ++pr) {
-        const int flA = wave * 4 + 2 * pr;
-        // ---- consume the fetched pair: pre-emphasis, RMS, window -> z = wA*yA + i*wB*yB
-        float2 v[16];
-        float ssA = 0.f, ssB = 0.f;
-        if (nfast) {
-#pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            const float xa = cvt(nxa[u]), xb = cvt(nxb[u]);
-            float ya = xa, yb = xb;
-            if (pre) {
-              // predecessor = previous lane's sample (wave_shr:1); lane 0 takes lane 63 of the row above
-              // (wave_ror:1 of u-1) or, for u = 0, the sample before the frame
-              const float oa = (u == 0) ? cvt(npa) : AFX_DPP(cvt(nxa[u > 0 ? u - 1 : 0]), 0x13C);
-              const float ob = (u == 0) ? cvt(npb) : AFX_DPP(cvt(nxb[u > 0 ? u - 1 : 0]), 0x13C);
-              const float pa = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(oa), __float_as_int(xa), 0x138, 0xf, 0xf, false));
-              const float pb = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ob), __float_as_int(xb), 0x138, 0xf, 0xf, false));
-              ya = preemph1(xa, pa, b1); yb = preemph1(xb, pb, b1);
-            }
-            ssA += ya * ya; ssB += yb * yb;
-            const float w = WT[lane + 64 * u];
-            v[u] = make_float2(w * ya, w * yb);
-          }
+      const int fl0 = wave * 4;
+      float2 v[16];
+      // ---- pair 0 (frames fl0, fl0+1): rows 0..19
+      if (rows_raw) {
+        if (pre) {
+          preemph_rows(rows, np_rows, std::integral_constant<int, 20>());
         } else {
-          const int jA = flA * hop + lane;
-#pragma unroll                    // (full unroll: v[] must keep compile-time indices to stay in registers)
-          for (int u = 0; u < 16; ++u) {
-            const float ya = edge_sample(cur, jA + 64 * u), yb = edge_sample(cur, jA + hop + 64 * u);
-            ssA += ya * ya; ssB += yb * yb;
-            const float w = WT[lane + 64 * u];
-            v[u] = make_float2(w * ya, w * yb);
-          }
-        }
-        ssA = wave_sum(ssA); ssB = wave_sum(ssB);
-        if (lane == 0) {
-          if (cur.t0 + flA < cur.T) rms_rows[cur.frame_slot + flA] = sqrtf(ssA / (float)N);
-          if (cur.t0 + flA + 1 < cur.T) rms_rows[cur.frame_slot + flA + 1] = sqrtf(ssB / (float)N);
-        }
-        if (pr == 0) flush_logmel();        // older than every load issued from here on
-        // ---- fetch the next pair (this block's second pair, or the next block's first)
-        if (pr == 0) issue_pair(cur, flA + 2); else issue_pair(nxt, wave * 4);
-
-        // ---- pass 1: radix 16 (no twiddles), exchange
-        dft16(v);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) EX[sA1 ^ r] = v[r];
+          for (int u = 0; u < 20; ++u) rows[u] = cvt(rows[u]);
+        }
+      } else {
+        // edge pair (clip start/end, trimmed span): clamped loads in a rolled loop (low register
+        // pressure, rare), parked in the exchange image and read back with static row indices
+#pragma unroll 1
+        for (int u = 0; u < 20; ++u) XB[64 * u + lane] = edge_sample(cur, fl0 * hop + lane + 64 * u);
         AFX_CBARRIER();
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = EX[(sR1 ^ ((u & 3) << 2)) + 64 * u];
-        AFX_CBARRIER();
-        // ---- pass 2: radix 8 x 2 butterflies (j = lane, lane + 64): inputs u = i + 2r, twiddle W_128^((lane&15) r)
-        {
-          float2 t2v[8];
-#pragma unroll
-          for (int r = 1; r < 8; ++r) t2v[r] = T2[(lane & 15) * 8 + r];
-          float2 xa[8], xb[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) { xa[r] = v[2 * r]; xb[r] = v[2 * r + 1]; }
-#pragma unroll
-          for (int r = 1; r < 8; ++r) { xa[r] = cmul(xa[r], t2v[r]); xb[r] = cmul(xb[r], t2v[r]); }
-          dft<8>(xa); dft<8>(xb);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) { EX[sW2a ^ (17 * r)] = xa[r]; EX[sW2b ^ (17 * r)] = xb[r]; }
-        }
-        AFX_CBARRIER();
-        // ---- pass 3: radix 8, butterflies ja = lane and jb = 128 - lane (lane 0: 0 and 64)
-        float2 A[8], B[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          A[r] = EX[(sRa ^ ((r & 1) << 3)) + 128 * r];
-          B[r] = EX[(sRb ^ ((r & 1) << 3)) + 128 * r];
-        }
-        AFX_CBARRIER();
-#pragma unroll
-        for (int r = 1; r < 8; ++r) { A[r] = cmul(A[r], tw3a[r - 1]); B[r] = cmul(B[r], tw3b[r - 1]); }
-        dft<8>(A); dft<8>(B);
-        // ---- A[r] = Z[lane + 128 r], B[r] = Z[128 - lane + 128 r]: pair s holds Z[k], Z[N-k] with
-        // k = lane + 128 s.  Lane 0 owns the self-mirrored butterflies 0 and 64 and pairs inside them.
-        const bool l0 = lane == 0;
-        float* const pcol = PB + flA;
-        auto power = [&](float2 za, float2 zb, int bin) {
-          const float ar = za.x + zb.x, ai = za.y - zb.y, br = za.y + zb.y, bi = za.x - zb.x;
-          pcol[bin * kPbStride] = ar * ar + ai * ai;           // |X_A[bin]|^2
-          pcol[bin * kPbStride + 1] = br * br + bi * bi;       // |X_B[bin]|^2
-        };
-        auto sel = [&](float2 a, float2 b) { return make_float2(l0 ? b.x : a.x, l0 ? b.y : a.y); };
-        power(sel(A[0], A[1]), sel(B[7], A[7]), l0 ? 128 : lane);
-        power(sel(A[1], A[2]), sel(B[6], A[6]), l0 ? 256 : lane + 128);
-        power(sel(A[2], A[3]), sel(B[5], A[5]), l0 ? 384 : lane + 256);
-        power(sel(A[3], B[0]), sel(B[4], B[7]), l0 ? 64 : lane + 384);
-        power(sel(A[4], B[1]), sel(B[3], B[6]), l0 ? 192 : 512 - lane);
-        power(sel(A[5], B[2]), sel(B[2], B[5]), l0 ? 320 : 384 - lane);
-        power(sel(A[6], B[3]), sel(B[1], B[4]), l0 ? 448 : 256 - lane);
-        power(sel(A[7], A[0]), sel(B[0], A[0]), l0 ? 0 : 128 - lane);
-        if (l0) {                                              // Nyquist bin from Z[512] = A[4]
-          pcol[512 * kPbStride] = 4.f * A[4].x * A[4].x;
-          pcol[512 * kPbStride + 1] = 4.f * A[4].y * A[4].y;
-        }
+        for (int u = 0; u < 20; ++u) rows[u] = XB[64 * u + lane];
         AFX_CBARRIER();
       }
+      stamp(ST_X0);
+      make_z(rows, v, cur, fl0);
+      stamp(ST_X1);
+      flush_logmel();                        // older than every load issued from here on
+      stamp(ST_X2);
+      issue_inc(cur);
+      fft_pair(v, fl0);
+      // ---- pair 1 (frames fl0+2, fl0+3): rows 8..27 = 12 kept rows + the 8 fetched ones
+      float r1[20];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) r1[u] = rows[u + 8];
+      if (inc_raw) {
+        if (pre) {
+          preemph_rows(inc, np_inc, std::integral_constant<int, 8>());
+#pragma unroll
+          for (int u = 0; u < 8; ++u) r1[12 + u] = inc[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) r1[12 + u] = cvt(inc[u]);
+        }
+      } else {
+#pragma unroll 1
+        for (int u = 0; u < 20; ++u) XB[64 * u + lane] = edge_sample(cur, (fl0 + 2) * hop + lane + 64 * u);
+        AFX_CBARRIER();
+#pragma unroll
+        for (int u = 0; u < 20; ++u) r1[u] = XB[64 * u + lane];
+        AFX_CBARRIER();
+      }
+      stamp(ST_X0);
+      make_z(r1, v, cur, fl0 + 2);
+      stamp(ST_X1);
+      issue_rows(nxt);                       // next block's first pair lands under this FFT and the mel phase
+      fft_pair(v, fl0 + 2);
     } else {
       flush_logmel();
-      issue_pair(nxt, wave * 4);
+      issue_rows(nxt);
     }
     stamp(ST_FFT);
     AFX_LDS_BARRIER();
@@ -1340,7 +1410,10 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
 #pragma unroll
       for (int i = 0; i < kMelRegItems; ++i) {
         if (i < mel_cnt) {
-          held[i] = mel_item(mi_b[i].z, mi_a[i].y, mi_a[i].z, mi_cf[i], mi_ko[i]);
+          const int ci = mi_a[i].x * 16 + f16;
+          const float4 cf = mel_lds ? MC4[ci] : tb.mel_coef[ci];
+          const float ko = mel_lds ? MCK[ci] : tb.mel_koff[ci];
+          held[i] = mel_item(mi_b[i].z, mi_a[i].y, mi_a[i].z, cf, ko);
           if (mi_a[i].w == 0) mel_finish(held[i], mi_a[i].x, lmh[i]);
           else if (mi_a[i].w == 1) *reinterpret_cast<f32x4*>(RB + mi_b[i].x * 256 + lane_m * 4) = held[i];
         }
@@ -1578,7 +1651,7 @@ static hipError_t launch_frames2_t(hipStream_t s, const void* samples, ClipInfo*
 hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
                          const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
                          float* logmel, float* rms_rows, int grid, unsigned long long* stamps) {
-  if (kp.n_fft == 1024 && !getenv("AFX_GENERIC_1024")) {
+  if (kp.n_fft == 1024 && kp.hop == 256 && !getenv("AFX_GENERIC_1024")) {
     if (kp.fmt == AFX_FMT_S16)
       return stamps ? launch_frames2_t<AFX_FMT_S16, true>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps)
                     : launch_frames2_t<AFX_FMT_S16, false>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
