@@ -1145,26 +1145,38 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   // 20 rows serves pair 0, 12 of them plus 8 new rows serve pair 1.  Rows are fetched raw (next block's
   // 20 rows under the second pair's FFT and the mel phase; the 8 new rows under the first pair's FFT),
   // pre-emphasised once in place, and shared by the two frames of a pair.
-  float rows[20], inc[8], np_rows = 0.f, np_inc = 0.f;
+  // Fetch: 16-byte loads (the texture-address unit charges per instruction, ~16 cycles per wave, whatever
+  // the width): lane l takes samples 4l..4l+3 of each 256-sample chunk -- 5 chunks for a 20-row window,
+  // 2 for the 8 new rows -- and the rows are re-cut through this wave's idle exchange image:
+  // written as 16-byte quads at float offset 4, read back as rows (offset 4) and as their left
+  // neighbours (offset 3; slot 3 holds the sample before the window).  S16 clips fetch 8 bytes per quad.
+  float rows[20], inc[8];
+  float4 qrows[5], qinc[2];
+  float np_rows = 0.f, np_inc = 0.f;
   bool rows_raw = false, inc_raw = false;              // false: the pair is an edge pair (clamped path)
-  auto raw_ld = [&](int64_t idx) -> float {            // bit pattern of one sample (converted at use)
-    if constexpr (FMT == AFX_FMT_S16) return __int_as_float((int)((const int16_t*)samples)[idx]);
+  auto raw_ld = [&](int64_t idx) -> float {            // one converted sample (edge path, predecessors)
+    if constexpr (FMT == AFX_FMT_S16) return (float)((const int16_t*)samples)[idx] * (1.0f / 32768.0f);
     else return ((const float*)samples)[idx];
   };
-  auto cvt = [&](float raw) -> float {
-    if constexpr (FMT == AFX_FMT_S16) return (float)__float_as_int(raw) * (1.0f / 32768.0f);
-    else return raw;
+  auto quad_ld = [&](int64_t idx) -> float4 {          // 4 consecutive samples, idx % 4 == 0
+    if constexpr (FMT == AFX_FMT_S16) {
+      const int2 q = *reinterpret_cast<const int2*>((const int16_t*)samples + idx);
+      const float sc = 1.0f / 32768.0f;
+      return make_float4((float)(short)(q.x & 0xffff) * sc, (float)(short)(q.x >> 16) * sc,
+                         (float)(short)(q.y & 0xffff) * sc, (float)(short)(q.y >> 16) * sc);
+    } else return *reinterpret_cast<const float4*>((const float*)samples + idx);
   };
   auto pair_is_interior = [&](const BlkCtx& c, int fl) -> bool {       // both frames: all samples and their
-    const int j0 = fl * hop, j1 = j0 + hop + N;                        // predecessors exist and are kept
-    return (j0 - 1 >= c.have_lo) && (j1 <= c.have_hi) && (j0 >= c.keep_lo) && (j1 <= c.keep_hi);
+    const int j0 = fl * hop, j1 = j0 + hop + N;                        // predecessors exist and are kept,
+    return (j0 - 1 >= c.have_lo) && (j1 <= c.have_hi) && (j0 >= c.keep_lo) && (j1 <= c.keep_hi) &&
+           ((c.sample_base & 3) == 0);                                 // and the quads are aligned
   };
   auto issue_rows = [&](const BlkCtx& c) {             // first pair of block c: rows 0..19
     rows_raw = c.active && pair_is_interior(c, wave * 4);
     if (rows_raw && !(kp.flags & 0x100)) {             // 0x100: timing-only ablation (stale registers)
       const int64_t ba = c.sample_base + (int64_t)(wave * 4) * hop;
 #pragma unroll
-      for (int u = 0; u < 20; ++u) rows[u] = raw_ld(ba + lane + 64 * u);
+      for (int ch = 0; ch < 5; ++ch) qrows[ch] = quad_ld(ba + 4 * lane + 256 * ch);
       np_rows = raw_ld(ba - 1);                        // wave-uniform address
     }
   };
@@ -1173,37 +1185,36 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     if (inc_raw && !(kp.flags & 0x100)) {
       const int64_t ba = c.sample_base + (int64_t)(wave * 4) * hop + 64 * 20;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) inc[u] = raw_ld(ba + lane + 64 * u);
+      for (int ch = 0; ch < 2; ++ch) qinc[ch] = quad_ld(ba + 4 * lane + 256 * ch);
       np_inc = raw_ld(ba - 1);
     }
   };
-  // In-place pre-emphasis of NR consecutive raw rows (p0 = the sample before the first row's lane 0).
-  // The left neighbour of a sample sits in the neighbouring lane, or across a row seam; rather than
-  // chasing it with cross-lane moves, the rows take a trip through this wave's (idle) exchange image:
-  // written at offset 1, read back at offset 0 -- both conflict-free ds_*_b32 rows.
   float* const XB = reinterpret_cast<float*>(EX);
-  auto preemph_rows = [&](float* r, float p0, auto NRt) {
-    constexpr int NR = decltype(NRt)::value;
+  // quads q[0..NCH) + predecessor p0 -> rows r[0..4*NCH), pre-emphasised when `pre`
+  auto cut_rows = [&](const float4* q, float p0, float* r, auto NCHt) {
+    constexpr int NCH = decltype(NCHt)::value, NR = 4 * NCH;
 #pragma unroll
-    for (int u = 0; u < NR; ++u) { r[u] = cvt(r[u]); XB[1 + 64 * u + lane] = r[u]; }
-    XB[0] = cvt(p0);
+    for (int ch = 0; ch < NCH; ++ch) *reinterpret_cast<float4*>(XB + 4 + 4 * lane + 256 * ch) = q[ch];
+    XB[3] = p0;
     AFX_CBARRIER();
     float prev[NR];
 #pragma unroll
-    for (int u = 0; u < NR; ++u) prev[u] = XB[64 * u + lane];
+    for (int u = 0; u < NR; ++u) { r[u] = XB[4 + 64 * u + lane]; prev[u] = XB[3 + 64 * u + lane]; }
     AFX_CBARRIER();
+    if (pre) {
 #pragma unroll
-    for (int u = 0; u < NR; ++u) r[u] = preemph1(r[u], prev[u], b1);
+      for (int u = 0; u < NR; ++u) r[u] = preemph1(r[u], prev[u], b1);
+    }
   };
   auto edge_sample = [&](const BlkCtx& c, int j) -> float {            // pre-emphasised, trim-masked sample j
     const int lo = c.have_lo, hi = c.have_hi - 1;
     const int jc = j < lo ? lo : (j > hi ? hi : j), jp = (j - 1) < lo ? lo : ((j - 1) > hi ? hi : (j - 1));
-    const float y = (jc == j) ? cvt(raw_ld(c.sample_base + jc)) : 0.f;
-    const float yp = (jp == j - 1) ? cvt(raw_ld(c.sample_base + jp)) : 0.f;
+    const float y = (jc == j) ? raw_ld(c.sample_base + jc) : 0.f;
+    const float yp = (jp == j - 1) ? raw_ld(c.sample_base + jp) : 0.f;
     float v = y;
     if (pre) {
       v = preemph1(y, yp, b1);
-      if (j == lo) v = preemph0(cvt(raw_ld(c.clip_off)), cvt(raw_ld(c.clip_off + 1)));   // clip sample 0
+      if (j == lo) v = preemph0(raw_ld(c.clip_off), raw_ld(c.clip_off + 1));   // clip sample 0
     }
     return (j >= c.keep_lo && j < c.keep_hi) ? v : 0.f;
   };
@@ -1288,6 +1299,10 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     }
   };
 
+  // experiment (AFX_DEBUG_SKIP bits 0x1000 / 0x2000): start half of the workgroups ~half a block late
+  if (((kp.flags & 0x1000) && blockIdx.x >= gridDim.x / 2) || ((kp.flags & 0x2000) && (blockIdx.x & 1))) {
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   BlkCtx cur = resolve(fetch_desc(blockIdx.x), blockIdx.x);
   int dnext = fetch_desc(blockIdx.x + gridDim.x);
   issue_rows(cur);
@@ -1303,12 +1318,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
       float2 v[16];
       // ---- pair 0 (frames fl0, fl0+1): rows 0..19
       if (rows_raw) {
-        if (pre) {
-          preemph_rows(rows, np_rows, std::integral_constant<int, 20>());
-        } else {
-#pragma unroll
-          for (int u = 0; u < 20; ++u) rows[u] = cvt(rows[u]);
-        }
+        cut_rows(qrows, np_rows, rows, std::integral_constant<int, 5>());
       } else {
         // edge pair (clip start/end, trimmed span): clamped loads in a rolled loop (low register
         // pressure, rare), parked in the exchange image and read back with static row indices
@@ -1331,14 +1341,9 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
 #pragma unroll
       for (int u = 0; u < 12; ++u) r1[u] = rows[u + 8];
       if (inc_raw) {
-        if (pre) {
-          preemph_rows(inc, np_inc, std::integral_constant<int, 8>());
+        cut_rows(qinc, np_inc, inc, std::integral_constant<int, 2>());
 #pragma unroll
-          for (int u = 0; u < 8; ++u) r1[12 + u] = inc[u];
-        } else {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) r1[12 + u] = cvt(inc[u]);
-        }
+        for (int u = 0; u < 8; ++u) r1[12 + u] = inc[u];
       } else {
 #pragma unroll 1
         for (int u = 0; u < 20; ++u) XB[64 * u + lane] = edge_sample(cur, (fl0 + 2) * hop + lane + 64 * u);
