@@ -47,7 +47,9 @@ struct afx_plan {
   std::vector<ClipDesc> h_clips;
   int nblocks = 0, max_tblocks = 0, max_tmax = 0;
   int64_t total_tpad = 0, total_tblk = 0;
-  std::vector<ClipInfo> h_info;
+  // pinned staging for the small per-call results (a device-to-pageable copy is staged and synchronous)
+  void* h_pin = nullptr;
+  size_t h_pin_cap = 0;
   // timing
   bool timing = false;
   hipEvent_t ev[AFX_K_COUNT][2] = {};
@@ -228,6 +230,7 @@ extern "C" void afx_plan_destroy(afx_plan* pl) {
   release(pl->samples); release(pl->clips); release(pl->info); release(pl->blocks); release(pl->bsum);
   release(pl->logmel); release(pl->rms); release(pl->mfcc); release(pl->stats); release(pl->frames);
   release(pl->frame_offs); release(pl->stamps);
+  if (pl->h_pin) (void)hipHostFree(pl->h_pin);
   if (pl->ev_ready)
     for (int k = 0; k < AFX_K_COUNT; ++k) { (void)hipEventDestroy(pl->ev[k][0]); (void)hipEventDestroy(pl->ev[k][1]); }
   delete pl;
@@ -387,9 +390,18 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
   TIMED(AFX_K_STATS, launch_stats(s, d_clips, d_info, kp, (const float*)pl->mfcc.p, (const float*)pl->rms.p,
                                   (float*)pl->stats.p, d_frames, (const int64_t*)pl->frame_offs.p, n));
 
-  pl->h_info.resize(n);
-  HIP_TRY(hipMemcpyAsync(out_stats, pl->stats.p, (size_t)n * nstat * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(pl->h_info.data(), d_info, n * sizeof(ClipInfo), hipMemcpyDeviceToHost, s));
+  const size_t stats_bytes = (size_t)n * nstat * sizeof(float), info_bytes = (size_t)n * sizeof(ClipInfo);
+  if (pl->h_pin_cap < stats_bytes + info_bytes) {
+    if (pl->h_pin) (void)hipHostFree(pl->h_pin);
+    pl->h_pin = nullptr; pl->h_pin_cap = 0;
+    const size_t want = (stats_bytes + info_bytes) * 5 / 4 + 256;          // slack covers the 16-byte round-up
+    HIP_TRY(hipHostMalloc(&pl->h_pin, want, hipHostMallocDefault));
+    pl->h_pin_cap = want;
+  }
+  float* h_stats = (float*)pl->h_pin;
+  const ClipInfo* h_info = (const ClipInfo*)((char*)pl->h_pin + ((stats_bytes + 15) & ~(size_t)15));
+  HIP_TRY(hipMemcpyAsync(h_stats, pl->stats.p, stats_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync((void*)h_info, d_info, info_bytes, hipMemcpyDeviceToHost, s));
   if (out_frames && frames_floats)
     HIP_TRY(hipMemcpyAsync(out_frames, d_frames, frames_floats * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -400,8 +412,9 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
       if (hipEventElapsedTime(&ms, pl->ev[k][0], pl->ev[k][1]) == hipSuccess) pl->ms_sum[k] += ms;
     }
   }
+  std::memcpy(out_stats, h_stats, stats_bytes);
   for (int i = 0; i < n; ++i) {
-    const ClipInfo& ci = pl->h_info[i];
+    const ClipInfo& ci = h_info[i];
     out_status[i] = ci.status;
     if (out_trim) { out_trim[2 * i] = ci.start; out_trim[2 * i + 1] = ci.end; }
     if (out_nframes) out_nframes[i] = ci.T;

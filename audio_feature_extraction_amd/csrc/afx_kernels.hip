@@ -603,11 +603,10 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
 #pragma unroll
       for (int i = 0; i < kMelRegItems; ++i) {
         if (i < mel_cnt && mi_a[i].w != 1) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = mi_a[i].x * 16 + q4 * 4 + r;
-            if (valid && m < M) tile[m * 16 + f16] = lmh[i][r];
-          }
+// tile layout [mel/4][frame][mel%4]: this lane's four filters are one 16-byte store
+          const int m0 = mi_a[i].x * 16 + q4 * 4;
+          if (valid && m0 < M)
+            *reinterpret_cast<float4*>(tile + (m0 >> 2) * 64 + f16 * 4) = make_float4(lmh[i][0], lmh[i][1], lmh[i][2], lmh[i][3]);
         }
       }
       const float mx = wave_max(pend_lmax);
@@ -911,7 +910,7 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
         const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc[r]));
         if (dst) dst[r] = Lv;
         if (valid && m < M) {
-          if (!dst && !(kp.flags & 0x800)) tile[m * 16 + f16] = Lv;
+          if (!dst && !(kp.flags & 0x800)) tile[(m >> 2) * 64 + f16 * 4 + (m & 3)] = Lv;
           lmax = fmaxf(lmax, Lv);
         }
       }
@@ -1129,11 +1128,10 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
 #pragma unroll
     for (int i = 0; i < kMelRegItems; ++i) {
       if (i < mel_cnt && mi_a[i].w != 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = mi_a[i].x * 16 + q4 * 4 + r;
-          if (valid && m < M) tile[m * 16 + f16] = lmh[i][r];
-        }
+// tile layout [mel/4][frame][mel%4]: this lane's four filters are one 16-byte store
+        const int m0 = mi_a[i].x * 16 + q4 * 4;
+        if (valid && m0 < M)
+          *reinterpret_cast<float4*>(tile + (m0 >> 2) * 64 + f16 * 4) = make_float4(lmh[i][0], lmh[i][1], lmh[i][2], lmh[i][3]);
       }
     }
     const float mx = wave_max(pend_lmax);
@@ -1405,7 +1403,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
         const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc[r]));
         if (dst) dst[r] = Lv;
         if (valid && m < M) {
-          if (!dst && !(kp.flags & 0x800)) tile[m * 16 + f16] = Lv;
+          if (!dst && !(kp.flags & 0x800)) tile[(m >> 2) * 64 + f16 * 4 + (m & 3)] = Lv;
           lmax = fmaxf(lmax, Lv);
         }
       }
@@ -1473,7 +1471,8 @@ __global__ __launch_bounds__(256) void k_dct(const ClipDesc* __restrict__ clips,
   const int M = kp.n_mels, K = kp.n_mfcc, NI = M >> 2;
   const float theta = ord2f(ci.lmax_ord) - kp.top_db;
   const int f = lane & 15, q = lane >> 4;
-  const float* tile = logmel + (cd.frame_base + t0) * (int64_t)M + lane;   // (4i + q)*16 + f = 64 i + lane
+  // tile layout [mel/4][frame][mel%4]: B[k = q][j = f] of k-step i is at 64 i + 4 f + q (one 256-B row per step)
+  const float* tile = logmel + (cd.frame_base + t0) * (int64_t)M + f * 4 + q;
   f32x4 acc[NCG];
 #pragma unroll
   for (int c = 0; c < NCG; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
