@@ -192,7 +192,7 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
   kp.trim_frame = p->trim_frame; kp.trim_hop = p->trim_hop;
   kp.preemph_b1 = (float)(-(double)p->preemph);     // np.asarray([1.0, -coef], dtype=float32)
   kp.trim_top_db = p->trim_top_db; kp.top_db = p->top_db; kp.amin = p->amin;
-  kp.flags = 0; kp.fmt = AFX_FMT_F32;
+  kp.flags = 0; kp.fmt = AFX_FMT_F32; kp.rms_sub = 0;
   int rc = AFX_OK;
   const HostTables& t = pl->ht;
   const int4* grp4 = nullptr;
@@ -205,6 +205,9 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
       (rc = upload(pl, t.mel.koff.data(), t.mel.koff.size(), &pl->dt.mel_koff)) != AFX_OK ||
       (rc = upload(pl, reinterpret_cast<const int4*>(t.mel.grp.data()), t.mel.grp.size() / 4, &grp4)) != AFX_OK ||
       (rc = upload(pl, reinterpret_cast<const int4*>(t.mel.items.data()), t.mel.items.size() / 4, &items4)) != AFX_OK ||
+      (rc = upload(pl, t.taps.taps.data(), t.taps.taps.size(), &pl->dt.mel_taps)) != AFX_OK ||
+      (rc = upload(pl, t.taps.meta.data(), t.taps.meta.size(), &pl->dt.mel_meta)) != AFX_OK ||
+      (rc = upload(pl, t.taps.order.data(), t.taps.order.size(), &pl->dt.mel_qorder)) != AFX_OK ||
       (rc = upload(pl, t.dctb.A.data(), t.dctb.A.size(), &pl->dt.dctA)) != AFX_OK) {
     afx_plan_destroy(pl);
     return rc;
@@ -214,7 +217,10 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
   pl->dt.mel_items = items4;
   for (int w = 0; w < 4; ++w) pl->dt.mel_item_cnt[w] = t.mel.item_cnt[w];
   pl->dt.mel_n_slots = t.mel.n_slots;
+  for (int w = 0; w < 4; ++w) pl->dt.mel_qcnt[w] = t.taps.cnt[w];
+  pl->dt.mel_ntaps = t.taps.usable ? (int32_t)t.taps.taps.size() : 0;
   pl->dt.n_groups = t.mel.n_groups;
+  kp.rms_sub = frames2_eligible(kp, pl->dt) ? kp.trim_hop / kp.hop : 0;
   pl->dt.n_cgroups = t.dctb.n_cgroups;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -325,7 +331,7 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
     d_samples = pl->samples.p;
   }
   if ((rc = ensure(pl->info, n * sizeof(ClipInfo))) != AFX_OK) return rc;
-  if ((rc = ensure(pl->bsum, std::max<int64_t>(pl->total_tblk, 1) * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->bsum, std::max<int64_t>(pl->total_tblk, 1) * 4 * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->logmel, (size_t)pl->total_tpad * M * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->rms, (size_t)pl->total_tpad * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->mfcc, (size_t)pl->total_tpad * K * sizeof(float))) != AFX_OK) return rc;
@@ -350,7 +356,7 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
 
   HIP_TRY(hipMemsetAsync(d_info, 0, n * sizeof(ClipInfo), s));
   TIMED(AFX_K_TRIM_BLOCKS, launch_trim_blocks(s, d_samples, d_clips, d_info, (float*)pl->bsum.p, n, pl->max_tblocks, kp));
-  TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, n, kp));
+  TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, (float*)pl->rms.p, n, kp));
   if (pl->nblocks > 0) {
     const int grid = std::min(pl->nblocks, pl->n_cu * 2);
     unsigned long long* d_stamps = nullptr;
@@ -461,7 +467,7 @@ extern "C" int afx_preprocess(afx_plan* pl, const float* y, int64_t n, float* ou
   if ((rc = prepare_descriptors(pl, &off, &n, 1)) != AFX_OK) return rc;
   if ((rc = ensure(pl->samples, (size_t)n * 4 + 16)) != AFX_OK) return rc;
   if ((rc = ensure(pl->info, sizeof(ClipInfo))) != AFX_OK) return rc;
-  if ((rc = ensure(pl->bsum, std::max<int64_t>(pl->total_tblk, 1) * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->bsum, std::max<int64_t>(pl->total_tblk, 1) * 4 * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->logmel, (size_t)std::max<int64_t>(n, 1) * sizeof(float))) != AFX_OK) return rc;   // y_pre scratch
   if (n > 0) HIP_TRY(hipMemcpyAsync(pl->samples.p, y, (size_t)n * 4, hipMemcpyHostToDevice, s));
   KParams kp = pl->kp;
@@ -469,7 +475,7 @@ extern "C" int afx_preprocess(afx_plan* pl, const float* y, int64_t n, float* ou
   ClipInfo* d_info = (ClipInfo*)pl->info.p;
   HIP_TRY(hipMemsetAsync(d_info, 0, sizeof(ClipInfo), s));
   HIP_TRY(launch_trim_blocks(s, pl->samples.p, (const ClipDesc*)pl->clips.p, d_info, (float*)pl->bsum.p, 1, pl->max_tblocks, kp));
-  HIP_TRY(launch_trim_decide(s, (const ClipDesc*)pl->clips.p, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, 1, kp));
+  HIP_TRY(launch_trim_decide(s, (const ClipDesc*)pl->clips.p, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, nullptr, 1, kp));
   if (n > 0) {
     HIP_TRY(launch_preemph(s, (const float*)pl->samples.p, (float*)pl->logmel.p, n, kp.preemph_b1));
     HIP_TRY(hipMemcpyAsync(out_y, pl->logmel.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));

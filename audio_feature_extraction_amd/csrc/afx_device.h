@@ -57,6 +57,11 @@ struct DevTables {
   const int4* mel_items;  // [4 waves][8 items][2 x int4]: group, b0, nb, role | slot, nslots, 0, 0
   int32_t mel_item_cnt[4];
   int32_t mel_n_slots;    // LDS partial-sum slots in use (0: no group is split)
+  const float* mel_taps;  // k_frames2: quad-padded tap weights
+  const int32_t* mel_meta; // k_frames2: per filter k0 | n4q << 10 | offset << 15
+  const int32_t* mel_qorder; // k_frames2: [4][kMelMaxQuads] quad ids
+  int32_t mel_qcnt[4];
+  int32_t mel_ntaps;      // floats in mel_taps (k_frames2 needs <= kMelTapCap)
   const float* dctA;     // DCT-II rows as MFMA A images
   int32_t n_groups;      // ceil(n_mels / 16)
   int32_t n_cgroups;     // ceil(n_mfcc / 16)
@@ -69,6 +74,8 @@ struct KParams {
   float trim_top_db, top_db, amin;
   int32_t flags;         // AFX_FLAG_*
   int32_t fmt;           // AFX_FMT_*
+  int32_t rms_sub;       // > 0: k_trim_blocks keeps sums per hop-sized sub-block (rms_sub per trim block) and
+                         // k_trim_decide derives the RMS rows from them (k_frames2 path); 0: the frame kernel computes RMS
 };
 
 // dynamic LDS bytes k_frames needs for (n_fft, hop); 0 if n_fft unsupported
@@ -77,7 +84,9 @@ size_t frames_lds_bytes(int n_fft, int hop);
 hipError_t launch_trim_blocks(hipStream_t s, const void* samples, const ClipDesc* clips, ClipInfo* info,
                               float* bsum, int n_clips, int max_tblocks, const KParams& kp);
 hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum,
-                              BlockDesc* blocks, int n_clips, const KParams& kp);
+                              BlockDesc* blocks, float* rms_rows, int n_clips, const KParams& kp);
+// true when launch_frames will take the n_fft = 1024 / hop = 256 kernel (k_frames2) for this plan
+bool frames2_eligible(const KParams& kp, const DevTables& tb);
 hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
                          const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
                          float* logmel, float* rms_rows, int grid, unsigned long long* stamps = nullptr);

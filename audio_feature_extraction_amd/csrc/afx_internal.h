@@ -31,6 +31,17 @@ struct MelBlocks {
   std::vector<float> koff;      // per (group, row): kmin - kc  (k - kc = koff + 4*blk + q)
 };
 
+// Tap tables for k_frames2's VALU mel stage.  Filters are taken four at a time (a "quad"); the four
+// lane-quarters of a wave split a filter's taps (tap i goes to quarter i % 4), so every filter of a
+// quad is padded with zero weights to the quad's longest tap count (a multiple of 4).
+struct MelTaps {
+  std::vector<float> taps;        // per quad: 4 filters x (4 * n4q) weights
+  std::vector<int32_t> meta;      // per filter: k0 | n4q << 10 | tap offset << 15
+  std::vector<int32_t> order;     // [4 waves][kMelMaxQuads] quad ids, dealt longest-first
+  int32_t cnt[4] = {0, 0, 0, 0};
+  bool usable = false;            // false: the generic kernel is used instead
+};
+
 // ortho DCT-II rows as MFMA A-operand images: dctA[(c * (n_mels/4) + i) * 64 + l] =
 // D[16c + (l & 15)][4i + (l >> 4)], zero for coefficient rows >= n_mfcc.
 struct DctBlocks {
@@ -45,6 +56,7 @@ struct HostTables {
   std::vector<float> tw;          // n_fft/2 complex: exp(-2*pi*i*n/(n_fft/2))
   std::vector<float> post;        // n_fft/2 complex: exp(-2*pi*i*k/n_fft)
   MelBlocks mel;
+  MelTaps taps;
   DctBlocks dctb;
 };
 

@@ -117,58 +117,76 @@ __global__ __launch_bounds__(256) void k_trim_blocks(const void* __restrict__ sa
   const int64_t i1 = (i0 + th < N) ? i0 + th : N;
   const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
   const float b1 = kp.preemph_b1;
+  // per > 1: the block's sum is kept as `per` sub-block sums of 256 samples (RMS rows are built from them)
+  const int per = kp.rms_sub > 0 ? kp.rms_sub : 1;
+  float* const dst = bsum + (cd.tblk_base + b) * per;
   float sum = 0.f;
   int nf = 0;
+  // Lane l takes samples 4l .. 4l+3 of every 256-sample run (one 16-byte load when the clip is float32 and
+  // aligned, guarded element loads otherwise); both routes add the squares in the same order, so the sums --
+  // and everything derived from them -- do not depend on how the clips were packed.
   const bool vec = kp.fmt == AFX_FMT_F32 && (((cd.off + i0) & 3) == 0) && ((th & 255) == 0) &&
                    (i1 - i0 == th) && i0 > 0;
-  if (vec) {
-    const float* base = (const float*)samples + cd.off;
-    for (int64_t i = i0 + 4 * lane; i < i1; i += 256) {
+  const float* base = (const float*)samples + cd.off;
+  int j = 0;
+  for (int64_t r0 = i0; r0 < i1; r0 += 256, ++j) {
+    const int64_t i = r0 + 4 * lane;
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f, prev = 0.f;
+    if (vec) {
       const float4 q = *reinterpret_cast<const float4*>(base + i);
-      float prev = __shfl_up(q.w, 1);
+      y0 = q.x; y1 = q.y; y2 = q.z; y3 = q.w;
+      prev = __shfl_up(q.w, 1);
       if (lane == 0) prev = base[i - 1];
-      nf |= !(isfinite(q.x) && isfinite(q.y) && isfinite(q.z) && isfinite(q.w));
-      float v0 = q.x, v1 = q.y, v2 = q.z, v3 = q.w;
-      if (pre) {
-        v0 = preemph1(q.x, prev, b1); v1 = preemph1(q.y, q.x, b1);
-        v2 = preemph1(q.z, q.y, b1); v3 = preemph1(q.w, q.z, b1);
-      }
-      sum += v0 * v0; sum += v1 * v1; sum += v2 * v2; sum += v3 * v3;
+    } else {
+      if (i < i1) y0 = ld_sample(samples, kp.fmt, cd.off + i);
+      if (i + 1 < i1) y1 = ld_sample(samples, kp.fmt, cd.off + i + 1);
+      if (i + 2 < i1) y2 = ld_sample(samples, kp.fmt, cd.off + i + 2);
+      if (i + 3 < i1) y3 = ld_sample(samples, kp.fmt, cd.off + i + 3);
+      if (i > 0 && i < i1) prev = ld_sample(samples, kp.fmt, cd.off + i - 1);
     }
-  } else {
-    for (int64_t i = i0 + lane; i < i1; i += 64) {
-      const float y = ld_sample(samples, kp.fmt, cd.off + i);
-      nf |= !isfinite(y);
-      float v = y;
-      if (pre) {
-        if (i == 0) v = (N > 1) ? preemph0(y, ld_sample(samples, kp.fmt, cd.off + 1)) : y;
-        else v = preemph1(y, ld_sample(samples, kp.fmt, cd.off + i - 1), b1);
-      }
-      sum += v * v;
+    nf |= !(isfinite(y0) && isfinite(y1) && isfinite(y2) && isfinite(y3));
+    float v0 = y0, v1 = y1, v2 = y2, v3 = y3;
+    if (pre) {
+      v0 = preemph1(y0, prev, b1); v1 = preemph1(y1, y0, b1);
+      v2 = preemph1(y2, y1, b1); v3 = preemph1(y3, y2, b1);
+      if (i == 0) v0 = (N > 1) ? preemph0(y0, y1) : y0;                       // clip sample 0
+      v0 = (i < i1) ? v0 : 0.f; v1 = (i + 1 < i1) ? v1 : 0.f;                 // past the clip end: nothing
+      v2 = (i + 2 < i1) ? v2 : 0.f; v3 = (i + 3 < i1) ? v3 : 0.f;
+    }
+    float s4 = v0 * v0; s4 += v1 * v1; s4 += v2 * v2; s4 += v3 * v3;
+    if (per > 1) {                         // th == 256 * per: this run is sub-block j
+      s4 = wave_sum(s4);
+      if (lane == 0) dst[j] = s4;
+    } else {
+      sum += s4;
     }
   }
-  sum = wave_sum(sum);
+  if (per > 1) {                           // a short last block: its missing sub-blocks are empty
+    for (int k = j; k < per; ++k) if (lane == 0) dst[k] = 0.f;
+  }
   nf = __any(nf);
-  if (lane == 0) {
-    bsum[cd.tblk_base + b] = sum;
-    if (nf) atomicOr(&info[clip].nonfinite, 1u);
+  if (per == 1) {
+    sum = wave_sum(sum);
+    if (lane == 0) dst[0] = sum;
   }
+  if (lane == 0 && nf) atomicOr(&info[clip].nonfinite, 1u);
 }
 
 // ---------------------------------------------------------------------------
 // k_trim_decide: one workgroup per clip
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float trim_frame_rms(const float* bs, int64_t t, int64_t nb, int half, float inv_n) {
+__device__ __forceinline__ float trim_frame_rms(const float* bs, int64_t t, int64_t nb, int half, int per, float inv_n) {
   float s = 0.f;
-  for (int64_t b = t - half; b < t + half; ++b)
-    if (b >= 0 && b < nb) s += bs[b];
+  for (int64_t b = (t - half) * per; b < (t + half) * per; ++b)     // bs holds `per` sums per trim block
+    if (b >= 0 && b < nb * per) s += bs[b];
   return sqrtf(s * inv_n);
 }
 
 __global__ __launch_bounds__(256) void k_trim_decide(const ClipDesc* __restrict__ clips,
                                                      ClipInfo* __restrict__ info,
                                                      const float* __restrict__ bsum,
-                                                     BlockDesc* __restrict__ blocks, KParams kp) {
+                                                     BlockDesc* __restrict__ blocks,
+                                                     float* __restrict__ rms_rows, KParams kp) {
   __shared__ float red_f[4];
   __shared__ long long red_a[4], red_b[4];
   const int clip = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -182,9 +200,10 @@ __global__ __launch_bounds__(256) void k_trim_decide(const ClipDesc* __restrict_
     const int th = kp.trim_hop, half = (kp.trim_frame / th) / 2;
     const int64_t nb = (N + th - 1) / th, nt = 1 + N / th;
     const float inv_n = 1.0f / (float)kp.trim_frame;
-    const float* bs = bsum + cd.tblk_base;
+    const int per = kp.rms_sub > 0 ? kp.rms_sub : 1;
+    const float* bs = bsum + cd.tblk_base * per;
     float mx = 0.f;
-    for (int64_t t = tid; t < nt; t += 256) mx = fmaxf(mx, trim_frame_rms(bs, t, nb, half, inv_n));
+    for (int64_t t = tid; t < nt; t += 256) mx = fmaxf(mx, trim_frame_rms(bs, t, nb, half, per, inv_n));
     mx = wave_max(mx);
     if (lane == 0) red_f[wave] = mx;
     __syncthreads();
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(256) void k_trim_decide(const ClipDesc* __restrict_
     const float ref_db = 10.0f * log10f(fmaxf(1e-10f, mx * mx));
     long long first = (long long)1 << 62, last = -1;
     for (int64_t t = tid; t < nt; t += 256) {
-      const float r = trim_frame_rms(bs, t, nb, half, inv_n);
+      const float r = trim_frame_rms(bs, t, nb, half, per, inv_n);
       const float db = 10.0f * log10f(fmaxf(1e-10f, r * r)) - ref_db;
       if (db > -kp.trim_top_db) { if (t < first) first = t; if (t > last) last = t; }
     }
@@ -219,6 +238,23 @@ __global__ __launch_bounds__(256) void k_trim_decide(const ClipDesc* __restrict_
     ci.start = start; ci.end = end; ci.T = T; ci.status = status; ci.lmax_ord = 0u;
     ci.nonfinite = info[clip].nonfinite;
     info[clip] = ci;
+  }
+  // RMS rows from the sub-block sums (feature_extractor.py:164, librosa.feature.rms center=True): frame t
+  // covers kept samples [start + t*hop - n_fft/2, + n_fft); start is a multiple of the sub-block (= hop),
+  // `end` is a multiple of it or the clip end, so the frame is a run of whole sub-blocks clipped to the kept span.
+  if (kp.rms_sub > 0 && rms_rows && status == AFX_CLIP_OK) {
+    const float* bs = bsum + cd.tblk_base * kp.rms_sub;
+    const int64_t s_lo = start / kp.hop, s_hi = (end + kp.hop - 1) / kp.hop;
+    const int nsb = kp.n_fft / kp.hop, back = nsb / 2;
+    const float inv_n = 1.0f / (float)kp.n_fft;
+    for (int t = tid; t < T; t += 256) {
+      float sacc = 0.f;
+      for (int k = 0; k < nsb; ++k) {
+        const int64_t sb = s_lo + t - back + k;
+        if (sb >= s_lo && sb < s_hi) sacc += bs[sb];
+      }
+      rms_rows[cd.frame_base + t] = sqrtf(sacc * inv_n);
+    }
   }
   // block descriptors of this clip for k_frames
   const int64_t lim = (int64_t)1 << 30;
@@ -254,7 +290,6 @@ struct FC {
 __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 
 constexpr int kPbStride = 17;   // power-spectrum rows: 16 frames + 1 pad (conflict-free column writes)
-constexpr int kPbPadRows = 3;   // zero rows past the Nyquist bin: mel blocks are 4 bins wide
 
 // n_fft = 1024 (the headline configuration) runs a hand-scheduled 8x8x8 core: XOR-swizzled
 // exchange image without padding, window / split twiddles in LDS, two frames in flight per wave.
@@ -972,17 +1007,17 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
 //     predecessor taken from the neighbouring lane (DPP); the next pair's loads fly under the FFT.
 // LDS: exchange images 32 KB + power-spectrum buffer 35 KB + window 4 KB + tables 3 KB = 75 KB.
 // ---------------------------------------------------------------------------
-struct Lds2 { int ex, pb, wt, t2, rb, t3, mc, total; };     // float offsets
+struct Lds2 { int ex, pb, wt, t2, t3, tp, mm, total; };     // float offsets
 __host__ __device__ inline Lds2 lds2_layout() {
   Lds2 L;
   L.ex = 0;
   L.pb = L.ex + kWaves * 1024 * 2;
   L.wt = L.pb + round4((513 + kPbPadRows) * kPbStride);
-  L.t2 = L.wt + 1024;
-  L.rb = L.t2 + 256;
-  L.t3 = L.rb + kMelMaxSlots * 256;        // last-pass twiddles of butterfly jb: 7 x 64 float2
-  L.mc = L.t3 + 7 * 64 * 2;                // mel triangle coefficients: 8 groups x 16 rows x (float4 + float)
-  L.total = L.mc + 8 * 16 * 5;
+  L.t2 = L.wt + 516;                        // half of the (symmetric) window, n = 0 .. 512
+  L.t3 = L.t2 + 256;                        // last-pass twiddles of butterfly jb: 7 x 64 float2
+  L.tp = L.t3 + 7 * 64 * 2;                 // mel tap weights, quad-padded
+  L.mm = L.tp + kMelTapCap;                 // per-filter meta words
+  L.total = L.mm + 128;
   return L;
 }
 size_t frames2_lds_bytes() { return (size_t)lds2_layout().total * sizeof(float); }
@@ -1045,10 +1080,9 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   float* const PB = smem + L.pb;
   float* const WT = smem + L.wt;
   float2* const T2 = reinterpret_cast<float2*>(smem + L.t2);
-  float* const RB = smem + L.rb;
   float2* const T3 = reinterpret_cast<float2*>(smem + L.t3);
-  float4* const MC4 = reinterpret_cast<float4*>(smem + L.mc);
-  float* const MCK = smem + L.mc + 8 * 16 * 4;
+  float* const TP = smem + L.tp;
+  int* const MM = reinterpret_cast<int*>(smem + L.mm);
 
   // ---- once per workgroup: tables -> LDS, per-lane twiddles -> registers
   for (int i = tid; i < kPbPadRows * kPbStride; i += 256) PB[NB * kPbStride + i] = 0.f;
@@ -1057,7 +1091,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     const float2 v = w1024[m & 511];
     return (m & 512) ? make_float2(-v.x, -v.y) : v;
   };
-  for (int i = tid; i < N; i += 256) WT[i] = 0.5f * tb.window[i];       // x0.5: the A/B split then needs no 1/2
+  for (int i = tid; i <= N / 2; i += 256) WT[i] = 0.5f * tb.window[i];  // x0.5: the A/B split then needs no 1/2
   if (tid < 128) T2[tid] = W(8 * (tid >> 4) * (tid & 15));              // pass-2 twiddles W_128^(c*r) at [r*16 + c]: a row per r,
                                                                          // so the 16 distinct c of a wave read 128 contiguous bytes
   const int ja = lane, jb = lane ? 128 - lane : 64;                      // last-pass butterflies of this lane
@@ -1068,8 +1102,8 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
 #pragma unroll
     for (int r = 1; r < 8; ++r) T3[(r - 1) * 64 + tid] = W(jb * r);
   }
-  const bool mel_lds = tb.n_groups <= 8;                                 // coefficient table fits its LDS slot
-  if (mel_lds && tid < tb.n_groups * 16) { MC4[tid] = tb.mel_coef[tid]; MCK[tid] = tb.mel_koff[tid]; }
+  for (int i = tid; i < tb.mel_ntaps; i += 256) TP[i] = tb.mel_taps[i];
+  if (tid < ((M + 3) & ~3)) MM[tid] = tb.mel_meta[tid];
   // exchange-image slots (see header): all per-lane bases
   const int sA1 = 16 * lane + (lane & 15);
   const int sR1 = lane ^ (lane >> 4);
@@ -1077,21 +1111,14 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   const int sW2b = sW2a + 512;                                           // butterfly j = lane + 64: x = (lane>>4) + 4, same parity
   const int sRa = ja ^ ((ja >> 4) & 7), sRb = jb ^ ((jb >> 4) & 7);
 
-  // mel work items of this wave (see k_frames)
+  // mel quads of this wave (host-balanced), ids in scalar registers
   const int mel_cnt = __builtin_amdgcn_readfirstlane(
-      tb.mel_item_cnt[0] * (wave == 0) + tb.mel_item_cnt[1] * (wave == 1) +
-      tb.mel_item_cnt[2] * (wave == 2) + tb.mel_item_cnt[3] * (wave == 3));
-  int4 mi_a[kMelRegItems], mi_b[kMelRegItems];
+      tb.mel_qcnt[0] * (wave == 0) + tb.mel_qcnt[1] * (wave == 1) +
+      tb.mel_qcnt[2] * (wave == 2) + tb.mel_qcnt[3] * (wave == 3));
+  int mq[kMelMaxQuads];
 #pragma unroll
-  for (int i = 0; i < kMelRegItems; ++i) {
-    mi_a[i] = make_int4(0, 0, 0, 0); mi_b[i] = make_int4(0, 0, 0, 0);
-    if (i < mel_cnt) {
-      auto sg = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-      const int4 a = tb.mel_items[(wave * kMelMaxItems + i) * 2], bb = tb.mel_items[(wave * kMelMaxItems + i) * 2 + 1];
-      mi_a[i] = make_int4(sg(a.x), sg(a.y), sg(a.z), sg(a.w));
-      mi_b[i] = make_int4(sg(bb.x), sg(bb.y), sg(tb.mel_grp[a.x].x), 0);
-    }
-  }
+  for (int i = 0; i < kMelMaxQuads; ++i)
+    mq[i] = i < mel_cnt ? __builtin_amdgcn_readfirstlane(tb.mel_qorder[wave * kMelMaxQuads + i]) : 0;
   const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
   const float b1 = kp.preemph_b1;
 
@@ -1112,7 +1139,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   };
 
   // deferred log-mel stores (see k_frames)
-  float lmh[kMelRegItems][4];
+  float lmh[kMelMaxQuads];
   bool pend = false;
   float pend_lmax = -INFINITY;
   int64_t pend_slot = 0;
@@ -1124,15 +1151,11 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     asm volatile("" : "+v"(lane_f));
     const int f16 = lane_f & 15, q4 = lane_f >> 4;
     const bool valid = (pend_t0 + f16) < pend_T;
-    float* tile = logmel + pend_slot * (int64_t)M;
+    float* tile = logmel + pend_slot * (int64_t)M + f16 * 4 + q4;
+    // tile layout [mel/4][frame][mel%4]: a quad is 64 consecutive floats, lane (f16, q4) owns filter 4*qd + q4
 #pragma unroll
-    for (int i = 0; i < kMelRegItems; ++i) {
-      if (i < mel_cnt && mi_a[i].w != 1) {
-// tile layout [mel/4][frame][mel%4]: this lane's four filters are one 16-byte store
-        const int m0 = mi_a[i].x * 16 + q4 * 4;
-        if (valid && m0 < M)
-          *reinterpret_cast<float4*>(tile + (m0 >> 2) * 64 + f16 * 4) = make_float4(lmh[i][0], lmh[i][1], lmh[i][2], lmh[i][3]);
-      }
+    for (int i = 0; i < kMelMaxQuads; ++i) {
+      if (i < mel_cnt && valid && mq[i] * 4 + q4 < M) tile[mq[i] * 64] = lmh[i];
     }
     const float mx = wave_max(pend_lmax);
     if (lane_f == 0 && mx > -INFINITY) atomicMax(&info[pend_clip].lmax_ord, f2ord(mx));
@@ -1281,19 +1304,12 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     AFX_CBARRIER();
     stamp(ST_FFT);
   };
-  // window + RMS of the pair whose frame A is rows y[0..15] and frame B rows y[4..19]
+  // window the pair whose frame A is rows y[0..15] and frame B rows y[4..19] (RMS rows come from k_trim_decide)
   auto make_z = [&](const float (&y)[20], float2 (&v)[16], const BlkCtx& c, int flA) {
-    float ssA = 0.f, ssB = 0.f;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      ssA += y[u] * y[u]; ssB += y[u + 4] * y[u + 4];
-      const float w = WT[lane + 64 * u];
+      const float w = u < 8 ? WT[lane + 64 * u] : WT[(64 - lane) + 64 * (15 - u)];   // w[n] = w[N - n]
       v[u] = make_float2(w * y[u], w * y[u + 4]);
-    }
-    ssA = wave_sum(ssA); ssB = wave_sum(ssB);
-    if (lane == 0) {
-      if (c.t0 + flA < c.T) rms_rows[c.frame_slot + flA] = sqrtf(ssA / (float)N);
-      if (c.t0 + flA + 1 < c.T) rms_rows[c.frame_slot + flA + 1] = sqrtf(ssB / (float)N);
     }
   };
 
@@ -1363,86 +1379,75 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     AFX_LDS_BARRIER();
     stamp(ST_BAR2);
 
-    // ---- mel filterbank + dB on the matrix pipe (as k_frames)
+    // ---- mel filterbank + dB on the vector pipe.  A mel row touches only its own ~2..60 bins, so as a matrix
+    // product it is >85 % zeros even block-sparse; here every multiply is a real tap.  Filters are taken four
+    // at a time (a quad): lane (f16, q4) walks the taps of filter 4*qd + q4 for frame f16 -- one P read, one
+    // weight read (broadcast within the quarter) and one FMA per tap, 8 taps in flight ahead of the FMAs.
     const bool mel_on = cur.active && !(kp.flags & 0x400);
-    int lane_m = lane;
-    asm volatile("" : "+v"(lane_m));
-    const int f16 = lane_m & 15, q4 = lane_m >> 4;
-    const bool valid = (cur.t0 + f16) < cur.T;
-    float lmax = -INFINITY;
-    float* tile = logmel + cur.frame_slot * (int64_t)M;
-    auto mel_item = [&](int kmin, int b0, int nb, const float4 cf, const float ko) -> f32x4 {
-      const float* p0 = PB + (kmin + 4 * b0 + q4) * kPbStride + f16;
-      const float* const pmax = PB + (NB + kPbPadRows - 1) * kPbStride + f16;
-      float kf = (float)(q4 + 4 * b0) + ko;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      for (int bk = 0; bk < nb; bk += 8) {
-        float pb[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float* p = p0 + i * 4 * kPbStride;
-          pb[i] = *(p < pmax ? p : pmax);
-        }
-        p0 += 8 * 4 * kPbStride;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float lo = fmaf(cf.y, kf, cf.x), hi = fmaf(cf.w, kf, cf.z);
-          float w = __builtin_amdgcn_fmed3f(0.f, lo, hi);
-          w = (bk + i < nb) ? w : 0.f;
-          if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc1, 0, 0, 0);
-          else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, pb[i], acc0, 0, 0, 0);
-          kf += 4.0f;
-        }
-      }
-      return acc0 + acc1;
-    };
-    auto mel_finish = [&](const f32x4 acc, int g, float* dst) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = g * 16 + q4 * 4 + r;
-        const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc[r]));
-        if (dst) dst[r] = Lv;
-        if (valid && m < M) {
-          if (!dst && !(kp.flags & 0x800)) tile[(m >> 2) * 64 + f16 * 4 + (m & 3)] = Lv;
-          lmax = fmaxf(lmax, Lv);
-        }
-      }
-    };
-    f32x4 held[kMelRegItems];
     if (mel_on) {
+      int lane_m = lane;
+      asm volatile("" : "+v"(lane_m));
+      const int f16 = lane_m & 15, q4 = lane_m >> 4;
+      const bool valid = (cur.t0 + f16) < cur.T;
+      float lmax = -INFINITY;
+      int mw[kMelMaxQuads];
 #pragma unroll
-      for (int i = 0; i < kMelRegItems; ++i) {
-        if (i < mel_cnt) {
-          const int ci = mi_a[i].x * 16 + f16;
-          const float4 cf = mel_lds ? MC4[ci] : tb.mel_coef[ci];
-          const float ko = mel_lds ? MCK[ci] : tb.mel_koff[ci];
-          held[i] = mel_item(mi_b[i].z, mi_a[i].y, mi_a[i].z, cf, ko);
-          if (mi_a[i].w == 0) mel_finish(held[i], mi_a[i].x, lmh[i]);
-          else if (mi_a[i].w == 1) *reinterpret_cast<f32x4*>(RB + mi_b[i].x * 256 + lane_m * 4) = held[i];
-        }
-      }
-      for (int i = kMelRegItems; i < mel_cnt; ++i) {
-        const int4 ia = tb.mel_items[(wave * kMelMaxItems + i) * 2];
-        const f32x4 acc = mel_item(tb.mel_grp[ia.x].x, ia.y, ia.z, tb.mel_coef[ia.x * 16 + f16], tb.mel_koff[ia.x * 16 + f16]);
-        mel_finish(acc, ia.x, nullptr);
-      }
-    }
-    stamp(ST_MEL);
-    AFX_LDS_BARRIER();      // PB is free for the next block's spectra; split groups' partial sums are in RB
-    stamp(ST_BAR3);
-    if (mel_on) {
+      for (int it = 0; it < kMelMaxQuads; ++it) mw[it] = it < mel_cnt ? MM[4 * mq[it] + q4] : 0;
 #pragma unroll
-      for (int i = 0; i < kMelRegItems; ++i) {
-        if (i < mel_cnt && mi_a[i].w == 2) {
-          f32x4 acc = held[i];
-          for (int sl = 0; sl < mi_b[i].y; ++sl)
-            acc += *reinterpret_cast<const f32x4*>(RB + (mi_b[i].x + sl) * 256 + lane_m * 4);
-          mel_finish(acc, mi_a[i].x, lmh[i]);
+      for (int it = 0; it < kMelMaxQuads; ++it) {
+        if (it < mel_cnt) {
+          const int n4 = __builtin_amdgcn_readfirstlane(mw[it] >> 10) & 31;   // same for the four filters of a quad
+          const float* p = PB + (mw[it] & 1023) * kPbStride + f16;
+          const float4* w = reinterpret_cast<const float4*>(TP + (mw[it] >> 15));
+          float a0 = 0.f, a1 = 0.f;
+          float x[8], xn[8];
+          float4 c0, c1, cn0, cn1;
+          auto ld8 = [&](float (&xx)[8], float4& ca, float4& cb) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) xx[t] = p[t * kPbStride];
+            ca = w[0]; cb = w[1];
+          };
+          auto fm8 = [&]() {
+            a0 = fmaf(c0.x, x[0], a0); a1 = fmaf(c0.y, x[1], a1); a0 = fmaf(c0.z, x[2], a0); a1 = fmaf(c0.w, x[3], a1);
+            a0 = fmaf(c1.x, x[4], a0); a1 = fmaf(c1.y, x[5], a1); a0 = fmaf(c1.z, x[6], a0); a1 = fmaf(c1.w, x[7], a1);
+          };
+          const int nfull = n4 >> 1;
+          if (nfull > 0) {
+            ld8(x, c0, c1);
+            for (int bq = 1; bq < nfull; ++bq) {
+              p += 8 * kPbStride; w += 2;
+              ld8(xn, cn0, cn1);
+              fm8();
+#pragma unroll
+              for (int t = 0; t < 8; ++t) x[t] = xn[t];
+              c0 = cn0; c1 = cn1;
+            }
+            if (n4 & 1) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) xn[t] = p[(8 + t) * kPbStride];
+              cn0 = w[2];
+              fm8();
+              a0 = fmaf(cn0.x, xn[0], a0); a1 = fmaf(cn0.y, xn[1], a1); a0 = fmaf(cn0.z, xn[2], a0); a1 = fmaf(cn0.w, xn[3], a1);
+            } else {
+              fm8();
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = p[t * kPbStride];
+            c0 = w[0];
+            a0 = fmaf(c0.x, x[0], a0); a1 = fmaf(c0.y, x[1], a1); a0 = fmaf(c0.z, x[2], a0); a1 = fmaf(c0.w, x[3], a1);
+          }
+          const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, a0 + a1));
+          lmh[it] = Lv;
+          if (valid && mq[it] * 4 + q4 < M) lmax = fmaxf(lmax, Lv);
         }
       }
       pend = true;
       pend_lmax = lmax; pend_slot = cur.frame_slot; pend_t0 = cur.t0; pend_T = cur.T; pend_clip = cur.clip;
     }
+    stamp(ST_MEL);
+    AFX_LDS_BARRIER();      // PB is free for the next block's spectra
+    stamp(ST_BAR3);
     stamp(ST_MELFIN);
     cur = nxt;
   }
@@ -1601,9 +1606,15 @@ hipError_t launch_trim_blocks(hipStream_t s, const void* samples, const ClipDesc
 }
 
 hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum,
-                              BlockDesc* blocks, int n_clips, const KParams& kp) {
-  hipLaunchKernelGGL(k_trim_decide, dim3(n_clips), dim3(256), 0, s, clips, info, bsum, blocks, kp);
+                              BlockDesc* blocks, float* rms_rows, int n_clips, const KParams& kp) {
+  hipLaunchKernelGGL(k_trim_decide, dim3(n_clips), dim3(256), 0, s, clips, info, bsum, blocks, rms_rows, kp);
   return hipGetLastError();
+}
+
+bool frames2_eligible(const KParams& kp, const DevTables& tb) {
+  const int per = kp.hop > 0 ? kp.trim_hop / kp.hop : 0;
+  return kp.n_fft == 1024 && kp.hop == 256 && tb.mel_ntaps > 0 && tb.mel_ntaps <= kMelTapCap && kp.n_mels <= 128 &&
+         kp.trim_hop % kp.hop == 0 && per >= 1 && per <= 4 && !getenv("AFX_GENERIC_1024");
 }
 
 template <int NFFT>
@@ -1655,7 +1666,7 @@ static hipError_t launch_frames2_t(hipStream_t s, const void* samples, ClipInfo*
 hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
                          const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
                          float* logmel, float* rms_rows, int grid, unsigned long long* stamps) {
-  if (kp.n_fft == 1024 && kp.hop == 256 && !getenv("AFX_GENERIC_1024")) {
+  if (frames2_eligible(kp, tb) && kp.rms_sub > 0) {
     if (kp.fmt == AFX_FMT_S16)
       return stamps ? launch_frames2_t<AFX_FMT_S16, true>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps)
                     : launch_frames2_t<AFX_FMT_S16, false>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
