@@ -99,8 +99,26 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // ---------------------------------------------------------------------------
-// k_trim_blocks: one wave per trim block (trim_hop samples) of one clip
+// k_trim_blocks: sums of squares of the (pre-emphasised) samples per trim block -- the only full pass over the
+// samples besides the frame kernel.  A wave owns kTrimPerWave consecutive trim blocks of one clip; when they are
+// all interior, float32 and 16-byte aligned it issues every load of its span before the first use.
 // ---------------------------------------------------------------------------
+constexpr int kTrimPerWave = 4;
+
+__device__ __forceinline__ float sumsq4(float v0, float v1, float v2, float v3) {
+#pragma clang fp contract(off)      // one rounding sequence wherever this is inlined
+  float s4 = v0 * v0; s4 += v1 * v1; s4 += v2 * v2; s4 += v3 * v3;
+  return s4;
+}
+__device__ __forceinline__ float sq4(float y0, float y1, float y2, float y3, float prev, bool pre, float b1) {
+  float v0 = y0, v1 = y1, v2 = y2, v3 = y3;
+  if (pre) {
+    v0 = preemph1(y0, prev, b1); v1 = preemph1(y1, y0, b1);
+    v2 = preemph1(y2, y1, b1); v3 = preemph1(y3, y2, b1);
+  }
+  return sumsq4(v0, v1, v2, v3);
+}
+
 __global__ __launch_bounds__(256) void k_trim_blocks(const void* __restrict__ samples,
                                                      const ClipDesc* __restrict__ clips,
                                                      ClipInfo* __restrict__ info,
@@ -111,64 +129,98 @@ __global__ __launch_bounds__(256) void k_trim_blocks(const void* __restrict__ sa
   const int64_t N = cd.len;
   const int th = kp.trim_hop;
   const int64_t nb = (N + th - 1) / th;
-  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
-  if (b >= nb) return;
-  const int64_t i0 = b * th;
-  const int64_t i1 = (i0 + th < N) ? i0 + th : N;
+  const int64_t bfirst = ((int64_t)blockIdx.x * 4 + wave) * kTrimPerWave;
+  if (bfirst >= nb) return;
   const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
   const float b1 = kp.preemph_b1;
-  // per > 1: the block's sum is kept as `per` sub-block sums of 256 samples (RMS rows are built from them)
+  // per > 1: a block's sum is kept as `per` sub-block sums of 256 samples (RMS rows are built from them)
   const int per = kp.rms_sub > 0 ? kp.rms_sub : 1;
-  float* const dst = bsum + (cd.tblk_base + b) * per;
-  float sum = 0.f;
-  int nf = 0;
-  // Lane l takes samples 4l .. 4l+3 of every 256-sample run (one 16-byte load when the clip is float32 and
-  // aligned, guarded element loads otherwise); both routes add the squares in the same order, so the sums --
-  // and everything derived from them -- do not depend on how the clips were packed.
-  const bool vec = kp.fmt == AFX_FMT_F32 && (((cd.off + i0) & 3) == 0) && ((th & 255) == 0) &&
-                   (i1 - i0 == th) && i0 > 0;
   const float* base = (const float*)samples + cd.off;
-  int j = 0;
-  for (int64_t r0 = i0; r0 < i1; r0 += 256, ++j) {
-    const int64_t i = r0 + 4 * lane;
-    float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f, prev = 0.f;
-    if (vec) {
-      const float4 q = *reinterpret_cast<const float4*>(base + i);
-      y0 = q.x; y1 = q.y; y2 = q.z; y3 = q.w;
-      prev = __shfl_up(q.w, 1);
-      if (lane == 0) prev = base[i - 1];
-    } else {
+  int nf = 0;
+
+  // fast route: the wave's whole span is inside the clip, float32, aligned, and made of 256-sample runs
+  const int64_t s0 = bfirst * th, s1 = s0 + (int64_t)kTrimPerWave * th;
+  const bool fast = kp.fmt == AFX_FMT_F32 && (th == 256 || th == 512) && s0 > 0 && s1 <= N && (((cd.off + s0) & 3) == 0);
+  if (fast) {
+    constexpr int MAXR = kTrimPerWave * 2;
+    const int nr = kTrimPerWave * (th >> 8);
+    float4 q[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+      if (r < nr) q[r] = *reinterpret_cast<const float4*>(base + s0 + 256 * r + 4 * lane);
+    float carry = base[s0 - 1];                                 // sample before the span (lane 0 of run 0)
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      if (r < nr) {
+        float prev = __shfl_up(q[r].w, 1);
+        if (lane == 0) prev = carry;
+        carry = __shfl(q[r].w, 63);
+        nf |= !(isfinite(q[r].x) && isfinite(q[r].y) && isfinite(q[r].z) && isfinite(q[r].w));
+        const float s4 = sq4(q[r].x, q[r].y, q[r].z, q[r].w, prev, pre, b1);
+        if (per > 1 || th == 256) {                             // every run is its own sum
+          const float t = wave_sum(s4);
+          if (lane == 0) bsum[(cd.tblk_base + bfirst) * per + r] = t;
+        } else {                                                // th == 512, one sum per block
+          acc += s4;
+          if (r & 1) {
+            const float t = wave_sum(acc);
+            if (lane == 0) bsum[cd.tblk_base + bfirst + (r >> 1)] = t;
+            acc = 0.f;
+          }
+        }
+      }
+    }
+    nf = __any(nf);
+    if (lane == 0 && nf) atomicOr(&info[clip].nonfinite, 1u);
+    return;
+  }
+
+  // general route (clip head and tail, int16 input, unaligned packing): same order of additions as above --
+  // lane l takes samples 4l .. 4l+3 of every 256-sample run -- so the sums, and everything derived from them,
+  // do not depend on how the clips were packed.
+  for (int k = 0; k < kTrimPerWave; ++k) {
+    const int64_t b = bfirst + k;
+    if (b >= nb) break;
+    const int64_t i0 = b * th;
+    const int64_t i1 = (i0 + th < N) ? i0 + th : N;
+    float* const dst = bsum + (cd.tblk_base + b) * per;
+    float sum = 0.f;
+    int j = 0;
+    for (int64_t r0 = i0; r0 < i1; r0 += 256, ++j) {
+      const int64_t i = r0 + 4 * lane;
+      float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f, prev = 0.f;
       if (i < i1) y0 = ld_sample(samples, kp.fmt, cd.off + i);
       if (i + 1 < i1) y1 = ld_sample(samples, kp.fmt, cd.off + i + 1);
       if (i + 2 < i1) y2 = ld_sample(samples, kp.fmt, cd.off + i + 2);
       if (i + 3 < i1) y3 = ld_sample(samples, kp.fmt, cd.off + i + 3);
       if (i > 0 && i < i1) prev = ld_sample(samples, kp.fmt, cd.off + i - 1);
+      nf |= !(isfinite(y0) && isfinite(y1) && isfinite(y2) && isfinite(y3));
+      float s4;
+      if (pre && (i == 0 || i + 3 >= i1)) {                     // clip sample 0 / the clip end inside this quad
+        float v0 = preemph1(y0, prev, b1), v1 = preemph1(y1, y0, b1), v2 = preemph1(y2, y1, b1), v3 = preemph1(y3, y2, b1);
+        if (i == 0) v0 = (N > 1) ? preemph0(y0, y1) : y0;
+        v0 = (i < i1) ? v0 : 0.f; v1 = (i + 1 < i1) ? v1 : 0.f;
+        v2 = (i + 2 < i1) ? v2 : 0.f; v3 = (i + 3 < i1) ? v3 : 0.f;
+        s4 = sumsq4(v0, v1, v2, v3);
+      } else {
+        s4 = sq4(y0, y1, y2, y3, prev, pre, b1);
+      }
+      if (per > 1) {                       // th == 256 * per: this run is sub-block j
+        s4 = wave_sum(s4);
+        if (lane == 0) dst[j] = s4;
+      } else {
+        sum += s4;
+      }
     }
-    nf |= !(isfinite(y0) && isfinite(y1) && isfinite(y2) && isfinite(y3));
-    float v0 = y0, v1 = y1, v2 = y2, v3 = y3;
-    if (pre) {
-      v0 = preemph1(y0, prev, b1); v1 = preemph1(y1, y0, b1);
-      v2 = preemph1(y2, y1, b1); v3 = preemph1(y3, y2, b1);
-      if (i == 0) v0 = (N > 1) ? preemph0(y0, y1) : y0;                       // clip sample 0
-      v0 = (i < i1) ? v0 : 0.f; v1 = (i + 1 < i1) ? v1 : 0.f;                 // past the clip end: nothing
-      v2 = (i + 2 < i1) ? v2 : 0.f; v3 = (i + 3 < i1) ? v3 : 0.f;
-    }
-    float s4 = v0 * v0; s4 += v1 * v1; s4 += v2 * v2; s4 += v3 * v3;
-    if (per > 1) {                         // th == 256 * per: this run is sub-block j
-      s4 = wave_sum(s4);
-      if (lane == 0) dst[j] = s4;
+    if (per > 1) {                         // a short last block: its missing sub-blocks are empty
+      for (int kk = j; kk < per; ++kk) if (lane == 0) dst[kk] = 0.f;
     } else {
-      sum += s4;
+      sum = wave_sum(sum);
+      if (lane == 0) dst[0] = sum;
     }
-  }
-  if (per > 1) {                           // a short last block: its missing sub-blocks are empty
-    for (int k = j; k < per; ++k) if (lane == 0) dst[k] = 0.f;
   }
   nf = __any(nf);
-  if (per == 1) {
-    sum = wave_sum(sum);
-    if (lane == 0) dst[0] = sum;
-  }
   if (lane == 0 && nf) atomicOr(&info[clip].nonfinite, 1u);
 }
 
@@ -1111,14 +1163,11 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   const int sW2b = sW2a + 512;                                           // butterfly j = lane + 64: x = (lane>>4) + 4, same parity
   const int sRa = ja ^ ((ja >> 4) & 7), sRb = jb ^ ((jb >> 4) & 7);
 
-  // mel quads of this wave (host-balanced), ids in scalar registers
-  const int mel_cnt = __builtin_amdgcn_readfirstlane(
-      tb.mel_qcnt[0] * (wave == 0) + tb.mel_qcnt[1] * (wave == 1) +
-      tb.mel_qcnt[2] * (wave == 2) + tb.mel_qcnt[3] * (wave == 3));
-  int mq[kMelMaxQuads];
-#pragma unroll
-  for (int i = 0; i < kMelMaxQuads; ++i)
-    mq[i] = i < mel_cnt ? __builtin_amdgcn_readfirstlane(tb.mel_qorder[wave * kMelMaxQuads + i]) : 0;
+  // mel quads of this wave: quad NQ-1 - (4*it + (it odd ? 3 - wave : wave)), it = 0..7 -- a snake over the quads
+  // from the widest down, which balances the four waves because tap counts grow with the quad index.
+  // Computed where used from `wave` (never kept per quad: that would cost two dozen scalar registers).
+  const int NQ = (M + 3) >> 2;
+  auto quad_of = [&](int wv, int it) { return NQ - 1 - (4 * it + ((it & 1) ? 3 - wv : wv)); };
   const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
   const float b1 = kp.preemph_b1;
 
@@ -1152,10 +1201,13 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     const int f16 = lane_f & 15, q4 = lane_f >> 4;
     const bool valid = (pend_t0 + f16) < pend_T;
     float* tile = logmel + pend_slot * (int64_t)M + f16 * 4 + q4;
+    int wv = wave;
+    asm volatile("" : "+s"(wv));
     // tile layout [mel/4][frame][mel%4]: a quad is 64 consecutive floats, lane (f16, q4) owns filter 4*qd + q4
 #pragma unroll
     for (int i = 0; i < kMelMaxQuads; ++i) {
-      if (i < mel_cnt && valid && mq[i] * 4 + q4 < M) tile[mq[i] * 64] = lmh[i];
+      const int qd = quad_of(wv, i);
+      if (qd >= 0 && valid && qd * 4 + q4 < M) tile[qd * 64] = lmh[i];
     }
     const float mx = wave_max(pend_lmax);
     if (lane_f == 0 && mx > -INFINITY) atomicMax(&info[pend_clip].lmax_ord, f2ord(mx));
@@ -1390,12 +1442,15 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
       const int f16 = lane_m & 15, q4 = lane_m >> 4;
       const bool valid = (cur.t0 + f16) < cur.T;
       float lmax = -INFINITY;
+      int wv = wave;
+      asm volatile("" : "+s"(wv));
       int mw[kMelMaxQuads];
 #pragma unroll
-      for (int it = 0; it < kMelMaxQuads; ++it) mw[it] = it < mel_cnt ? MM[4 * mq[it] + q4] : 0;
+      for (int it = 0; it < kMelMaxQuads; ++it) { const int qd = quad_of(wv, it); mw[it] = qd >= 0 ? MM[4 * qd + q4] : 0; }
 #pragma unroll
       for (int it = 0; it < kMelMaxQuads; ++it) {
-        if (it < mel_cnt) {
+        const int qd = quad_of(wv, it);
+        if (qd >= 0) {
           const int n4 = __builtin_amdgcn_readfirstlane(mw[it] >> 10) & 31;   // same for the four filters of a quad
           const float* p = PB + (mw[it] & 1023) * kPbStride + f16;
           const float4* w = reinterpret_cast<const float4*>(TP + (mw[it] >> 15));
@@ -1439,7 +1494,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
           }
           const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, a0 + a1));
           lmh[it] = Lv;
-          if (valid && mq[it] * 4 + q4 < M) lmax = fmaxf(lmax, Lv);
+          if (valid && qd * 4 + q4 < M) lmax = fmaxf(lmax, Lv);
         }
       }
       pend = true;
@@ -1600,7 +1655,7 @@ __global__ __launch_bounds__(256) void k_preemph(const float* __restrict__ y, fl
 // ---------------------------------------------------------------------------
 hipError_t launch_trim_blocks(hipStream_t s, const void* samples, const ClipDesc* clips, ClipInfo* info,
                               float* bsum, int n_clips, int max_tblocks, const KParams& kp) {
-  dim3 grid((max_tblocks + 3) / 4, n_clips);
+  dim3 grid((max_tblocks + 4 * kTrimPerWave - 1) / (4 * kTrimPerWave), n_clips);
   hipLaunchKernelGGL(k_trim_blocks, grid, dim3(256), 0, s, samples, clips, info, bsum, kp);
   return hipGetLastError();
 }
