@@ -208,7 +208,8 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
       (rc = upload(pl, t.taps.taps.data(), t.taps.taps.size(), &pl->dt.mel_taps)) != AFX_OK ||
       (rc = upload(pl, t.taps.meta.data(), t.taps.meta.size(), &pl->dt.mel_meta)) != AFX_OK ||
       (rc = upload(pl, t.taps.order.data(), t.taps.order.size(), &pl->dt.mel_qorder)) != AFX_OK ||
-      (rc = upload(pl, t.dctb.A.data(), t.dctb.A.size(), &pl->dt.dctA)) != AFX_OK) {
+      (rc = upload(pl, t.dctb.A.data(), t.dctb.A.size(), &pl->dt.dctA)) != AFX_OK ||
+      (rc = upload(pl, t.dctb.P.data(), t.dctb.P.size(), &pl->dt.dctP)) != AFX_OK) {
     afx_plan_destroy(pl);
     return rc;
   }
@@ -222,6 +223,7 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
   pl->dt.n_groups = t.mel.n_groups;
   kp.rms_sub = frames2_eligible(kp, pl->dt) ? kp.trim_hop / kp.hop : 0;
   pl->dt.n_cgroups = t.dctb.n_cgroups;
+  if (t.dctb.P.size() < 64) pl->dt.dctP = nullptr;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
     pl->n_cu = prop.multiProcessorCount;

@@ -63,6 +63,7 @@ struct DevTables {
   int32_t mel_qcnt[4];
   int32_t mel_ntaps;      // floats in mel_taps (k_frames2 needs <= kMelTapCap)
   const float* dctA;     // DCT-II rows as MFMA A images
+  const float* dctP;     // the same, permuted for k_dct16's 16-byte tile loads (nullptr: not applicable)
   int32_t n_groups;      // ceil(n_mels / 16)
   int32_t n_cgroups;     // ceil(n_mfcc / 16)
 };

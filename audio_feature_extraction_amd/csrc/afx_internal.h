@@ -47,6 +47,7 @@ struct MelTaps {
 struct DctBlocks {
   int32_t n_cgroups = 0;        // ceil(n_mfcc / 16)
   std::vector<float> A;
+  std::vector<float> P;         // k_dct16 (n_mels % 16 == 0, n_mfcc <= 16): A images for 16-byte tile loads
 };
 
 struct HostTables {

@@ -1555,6 +1555,66 @@ __global__ __launch_bounds__(256) void k_dct(const ClipDesc* __restrict__ clips,
   }
 }
 
+// k_dct16: the same for n_mels % 16 == 0 and n_mfcc <= 16 (the reference's 128 / 13).  A wave takes kDctTiles
+// tiles; lane (f, q) fetches filters 16 s + 4 q + {0..3} of frame f with one 16-byte load (a wave-load is 1 KB
+// contiguous), all loads of its tiles issued before the first use; the DCT matrix sits in registers.
+constexpr int kDctTiles = 2;
+__global__ __launch_bounds__(256) void k_dct16(const ClipDesc* __restrict__ clips,
+                                               const ClipInfo* __restrict__ info,
+                                               const float* __restrict__ dctP, KParams kp,
+                                               const float* __restrict__ logmel,
+                                               float* __restrict__ mfcc) {
+  const int clip = blockIdx.y;
+  const ClipInfo ci = info[clip];
+  if (ci.status != AFX_CLIP_OK) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile0 = (blockIdx.x * 4 + wave) * kDctTiles;
+  if (tile0 * 16 >= ci.T) return;
+  const ClipDesc cd = clips[clip];
+  const int M = kp.n_mels, K = kp.n_mfcc, S = M >> 4;         // S <= 8
+  const float theta = ord2f(ci.lmax_ord) - kp.top_db;
+  const int f = lane & 15, q = lane >> 4;
+  float4 x[kDctTiles][8];
+#pragma unroll
+  for (int j = 0; j < kDctTiles; ++j) {
+    const int t0 = (tile0 + j) * 16;
+    // tiles past the clip's last frame are not read (t0 is wave-uniform); [mel/4][frame][mel%4]: quad row 4 s + q
+    const float* tile = logmel + (cd.frame_base + t0) * (int64_t)M + (q * 16 + f) * 4;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      x[j][s] = (s < S && t0 < ci.T) ? *reinterpret_cast<const float4*>(tile + s * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float a[8][4];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[s][c] = s < S ? dctP[(s * 4 + c) * 64 + lane] : 0.f;
+#pragma unroll
+  for (int j = 0; j < kDctTiles; ++j) {
+    const int t0 = (tile0 + j) * 16;
+    if (t0 >= ci.T) break;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < S) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], fmaxf(x[j][s].x, theta), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][1], fmaxf(x[j][s].y, theta), acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][2], fmaxf(x[j][s].z, theta), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], fmaxf(x[j][s].w, theta), acc1, 0, 0, 0);
+      }
+    }
+    const f32x4 acc = acc0 + acc1;
+    if (t0 + f < ci.T) {
+      float* out = mfcc + cd.frame_base * (int64_t)K + t0 + f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = q * 4 + r;
+        if (k < K) out[(int64_t)k * cd.tpad] = acc[r];
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // k_stats: one wave per (clip, row); rows 0..K-1 = MFCC coefficients, row K = RMS
 // ---------------------------------------------------------------------------
@@ -1739,6 +1799,11 @@ hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
 
 hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
                       const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax) {
+  if (tb.dctP && kp.n_mels % 16 == 0 && kp.n_mels <= 128 && kp.n_mfcc <= 16) {
+    dim3 g16(((max_tmax + 15) / 16 + 4 * kDctTiles - 1) / (4 * kDctTiles), n_clips);
+    hipLaunchKernelGGL(k_dct16, g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
+    return hipGetLastError();
+  }
   dim3 grid(((max_tmax + 15) / 16 + 3) / 4, n_clips);
   switch (tb.n_cgroups) {
     case 1: hipLaunchKernelGGL(k_dct<1>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
