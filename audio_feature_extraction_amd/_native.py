@@ -9,7 +9,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libafx.so")
+# AFX_LIB: developer override used to A/B two builds of the library on the same GPU box
+LIB_PATH = os.environ.get("AFX_LIB") or os.path.join(_HERE, "libafx.so")
 
 AFX_OK = 0
 CLIP_OK, CLIP_TOO_SHORT, CLIP_NONFINITE = 0, 1, 2
