@@ -12,7 +12,7 @@ Scaling is weak: every rank owns its own 1000 clips, no data-path collective; th
 torch.distributed traffic is the timing barrier and the max-over-ranks reduction.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     -- k_frames (dominant kernel): algorithmic bytes = 4*hop per frame (each
+  roofline     -- the frame kernel k_frames2 (dominant): algorithmic bytes = 4*hop per frame (each
                   input sample read once) / average launch duration from HIP events
                   recorded on the kernel's own stream inside the timed region;
   cpu_baseline -- the numpy/scipy oracle (a port of the reference's librosa path) timed
@@ -227,7 +227,7 @@ def main() -> None:
                 traffic = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                    "algorithmic_bytes_per_launch": frames_per_step * 4 * HOP, "kernel": "k_frames<1024>",
+                    "algorithmic_bytes_per_launch": frames_per_step * 4 * HOP, "kernel": "k_frames2 (n_fft=1024, hop=256)",
                     "avg_launch_ms": avg_ms,
                     "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in kt.items()}}
         line = {

@@ -37,7 +37,7 @@ typedef enum afx_status {
   AFX_ERR_NO_DEVICE = -2,   /* no usable HIP device */
   AFX_ERR_HIP = -3,         /* a HIP runtime call or kernel launch failed */
   AFX_ERR_NOMEM = -4,
-  AFX_ERR_UNSUPPORTED = -5  /* e.g. n_fft not a power of two in [256, 4096] */
+  AFX_ERR_UNSUPPORTED = -5  /* e.g. n_fft not a power of two in [256, 2048] */
 } afx_status;
 
 /* per-clip status written to out_status[] */
