@@ -26,7 +26,7 @@ SYMBOLS = (
     "afx_version", "afx_device_count", "afx_last_error", "afx_init", "afx_destroy",
     "afx_malloc", "afx_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
     "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables",
-    "afx_extract_batch", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings",
+    "afx_extract_batch", "afx_f0_batch", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings",
 )
 
 
@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
         L.afx_plan_destroy.argtypes = [vp]; L.afx_plan_destroy.restype = None
         L.afx_build_tables.argtypes = [C.POINTER(Params), vp, vp, vp]
         L.afx_extract_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+        L.afx_f0_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
         L.afx_preprocess.argtypes = [vp, vp, C.c_int64, vp, i64p, i64p, i32p]
         L.afx_plan_set_timing.argtypes = [vp, i32]
         L.afx_plan_get_timings.argtypes = [vp, vp, vp, i32]
@@ -243,6 +244,41 @@ class Plan:
                 res.append({"mfcc": blk[:K].copy(), "mfcc_delta": blk[K:2 * K].copy(),
                             "mfcc_delta2": blk[2 * K:3 * K].copy(), "rms": blk[3 * K:].copy()})
             out["frames"] = res
+        return out
+
+    def f0_batch(self, samples, offsets, lengths, fmin: float, fmax: float,
+                 flags=FLAG_PREEMPH | FLAG_TRIM, fmt=FMT_F32, want_frames: bool = False):
+        """extract_f0 (pYIN) of a ragged batch.  Returns stats [n, 4] float64 (f0_mean, f0_std,
+        f0_missing_rate, f0_quality), status [n] and, when asked, f0: list of per-frame arrays (NaN = unvoiced)."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        lengths = np.ascontiguousarray(lengths, np.int64)
+        n = int(offsets.shape[0])
+        out = {"stats": np.zeros((n, 4), np.float64), "status": np.zeros(n, np.int32)}
+        if isinstance(samples, np.ndarray):
+            want = np.int16 if fmt == FMT_S16 else np.float32
+            if samples.dtype != want or not samples.flags.c_contiguous:
+                raise ValueError(f"samples must be C-contiguous {want.__name__}")
+            if n and int((offsets + lengths).max()) > samples.size:
+                raise ValueError("clip extends past the sample buffer")
+            sptr, kind = samples.ctypes.data, MEM_HOST
+        else:
+            sptr = samples.ptr if isinstance(samples, DeviceBuffer) else int(samples)
+            kind = MEM_DEVICE
+        fptr = foffs_ptr = None
+        f0 = foffs = None
+        if want_frames:
+            tmax = 1 + lengths // self.params.hop
+            foffs = np.zeros(n, np.int64)
+            if n:
+                foffs[1:] = np.cumsum(tmax)[:-1]
+            f0 = np.full(int(tmax.sum()) if n else 0, np.nan, np.float64)
+            fptr, foffs_ptr = f0.ctypes.data, foffs.ctypes.data
+        rc = lib().afx_f0_batch(
+            self.handle, sptr, int(fmt), kind, offsets.ctypes.data, lengths.ctypes.data, n, int(flags),
+            C.c_double(fmin), C.c_double(fmax), out["stats"].ctypes.data, out["status"].ctypes.data, fptr, foffs_ptr)
+        _check(rc, "afx_f0_batch")
+        if want_frames:
+            out["f0_flat"], out["f0_offsets"] = f0, foffs
         return out
 
     def preprocess(self, y: np.ndarray):

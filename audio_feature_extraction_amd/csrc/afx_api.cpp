@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "afx_device.h"
+#include "afx_f0.h"
 #include "afx_internal.h"
 
 namespace afx {
@@ -42,6 +43,13 @@ struct afx_plan {
   DevTables dt{};
   std::vector<void*> table_allocs;
   DevBuf samples, clips, info, blocks, bsum, logmel, rms, mfcc, stats, frames, frame_offs, stamps;
+  // extract_f0 (pYIN): tables for the last (fmin, fmax) used and the stage's workspace
+  bool f0_ready = false;
+  double f0_fmin = 0.0, f0_fmax = 0.0;
+  HostF0Tables f0_ht;
+  F0Tables f0_dt{};
+  std::vector<void*> f0_allocs;
+  DevBuf f0_in, f0_ysig, f0_energy, f0_cnt, f0_vp, f0_bin, f0_prob, f0_ptr, f0_states, f0_stats, f0_out, f0_offs;
   // cached per-batch descriptors
   std::vector<int64_t> c_off, c_len;
   std::vector<ClipDesc> h_clips;
@@ -235,6 +243,10 @@ extern "C" void afx_plan_destroy(afx_plan* pl) {
   if (!pl) return;
   (void)hipSetDevice(pl->ctx->device);
   for (void* d : pl->table_allocs) (void)hipFree(d);
+  for (void* q : pl->f0_allocs) (void)hipFree(q);
+  release(pl->f0_in); release(pl->f0_ysig); release(pl->f0_energy); release(pl->f0_cnt); release(pl->f0_vp);
+  release(pl->f0_bin); release(pl->f0_prob); release(pl->f0_ptr); release(pl->f0_states); release(pl->f0_stats);
+  release(pl->f0_out); release(pl->f0_offs);
   release(pl->samples); release(pl->clips); release(pl->info); release(pl->blocks); release(pl->bsum);
   release(pl->logmel); release(pl->rms); release(pl->mfcc); release(pl->stats); release(pl->frames);
   release(pl->frame_offs); release(pl->stamps);
@@ -452,6 +464,141 @@ extern "C" int afx_extract_batch(afx_plan* pl, const void* samples, int sample_f
                            out_nframes ? out_nframes + c0 : nullptr, out_frames,
                            frame_offsets ? frame_offsets + c0 : nullptr);
     if (rc != AFX_OK) return rc;
+  }
+  return AFX_OK;
+}
+
+// ---- extract_f0 ---------------------------------------------------------------------------------
+static int f0_setup(afx_plan* pl, double fmin, double fmax) {
+  if (pl->f0_ready && pl->f0_fmin == fmin && pl->f0_fmax == fmax) return AFX_OK;
+  std::string why;
+  HostF0Tables ht;
+  if (!build_f0_tables(pl->p.sr, pl->p.n_fft, pl->p.hop, fmin, fmax, ht, why)) {
+    set_error("afx_f0_batch: " + why);
+    return AFX_ERR_UNSUPPORTED;
+  }
+  if (f0_energy_lds_bytes(ht.p) > 160 * 1024 || f0_yin_lds_bytes(ht.p) > 160 * 1024 ||
+      f0_viterbi_lds_bytes(ht.p) > 160 * 1024) {
+    set_error("afx_f0_batch: frame_length / f0 range needs more than 160 KiB of LDS");
+    return AFX_ERR_UNSUPPORTED;
+  }
+  for (void* q : pl->f0_allocs) (void)hipFree(q);
+  pl->f0_allocs.clear();
+  pl->f0_ready = false;
+  auto up = [&](const std::vector<double>& v, const double** dst) -> int {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, v.size() * sizeof(double)));
+    pl->f0_allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    *dst = (const double*)d;
+    return AFX_OK;
+  };
+  int rc;
+  if ((rc = up(ht.thr, &pl->f0_dt.thr)) != AFX_OK || (rc = up(ht.beta, &pl->f0_dt.beta)) != AFX_OK ||
+      (rc = up(ht.cumbeta, &pl->f0_dt.cumbeta)) != AFX_OK || (rc = up(ht.bfact, &pl->f0_dt.bfact)) != AFX_OK ||
+      (rc = up(ht.bexp, &pl->f0_dt.bexp)) != AFX_OK || (rc = up(ht.lt, &pl->f0_dt.lt)) != AFX_OK ||
+      (rc = up(ht.freqs, &pl->f0_dt.freqs)) != AFX_OK)
+    return rc;
+  pl->f0_ht = ht;
+  pl->f0_fmin = fmin; pl->f0_fmax = fmax;
+  pl->f0_ready = true;
+  return AFX_OK;
+}
+
+static int f0_chunk(afx_plan* pl, const void* d_samples, int fmt, const int64_t* offsets, const int64_t* lengths,
+                    int n, int flags, double* out_stats, int32_t* out_status, double* out_f0,
+                    const int64_t* f0_offsets) {
+  hipStream_t s = pl->ctx->stream;
+  const F0Params& fp = pl->f0_ht.p;
+  int rc;
+  if ((rc = prepare_descriptors(pl, offsets, lengths, n)) != AFX_OK) return rc;
+  int64_t hi = 0, max_len = 0;
+  for (int i = 0; i < n; ++i) { hi = std::max(hi, offsets[i] + lengths[i]); max_len = std::max(max_len, lengths[i]); }
+  const int64_t frames = std::max<int64_t>(pl->total_tpad, 1);
+  const size_t S = 2 * (size_t)fp.n_bins;
+  if ((rc = ensure(pl->info, n * sizeof(ClipInfo))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->bsum, std::max<int64_t>(pl->total_tblk, 1) * 4 * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_ysig, (size_t)std::max<int64_t>(hi, 1) * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_energy, (size_t)frames * fp.n_tau_pad * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_cnt, (size_t)frames * sizeof(int32_t))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_vp, (size_t)frames * sizeof(double))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_bin, f0_cand_bins_bytes(fp, frames))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_prob, f0_cand_prob_bytes(fp, frames))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_ptr, (size_t)frames * S * sizeof(uint16_t))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_states, (size_t)frames * sizeof(uint16_t))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_stats, (size_t)n * 4 * sizeof(double))) != AFX_OK) return rc;
+  double* d_f0 = nullptr;
+  size_t f0_count = 0;
+  if (out_f0) {
+    if (!f0_offsets) { set_error("out_f0 given without f0_offsets"); return AFX_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) f0_count = std::max<size_t>(f0_count, (size_t)f0_offsets[i] + (size_t)pl->h_clips[i].tmax);
+    if ((rc = ensure(pl->f0_out, f0_count * sizeof(double))) != AFX_OK) return rc;
+    if ((rc = ensure(pl->f0_offs, n * sizeof(int64_t))) != AFX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(pl->f0_offs.p, f0_offsets, n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    d_f0 = (double*)pl->f0_out.p;
+  }
+  KParams kp = pl->kp;
+  kp.flags = flags; kp.fmt = fmt;
+  const ClipDesc* d_clips = (const ClipDesc*)pl->clips.p;
+  ClipInfo* d_info = (ClipInfo*)pl->info.p;
+  HIP_TRY(hipMemsetAsync(d_info, 0, n * sizeof(ClipInfo), s));
+  HIP_TRY(launch_trim_blocks(s, d_samples, d_clips, d_info, (float*)pl->bsum.p, n, pl->max_tblocks, kp));
+  HIP_TRY(launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, nullptr, n, kp));
+  HIP_TRY(launch_f0_prep(s, d_samples, d_clips, d_info, (float*)pl->f0_ysig.p, n, max_len, kp));
+  HIP_TRY(launch_f0_energy(s, (const float*)pl->f0_ysig.p, d_clips, d_info, (float*)pl->f0_energy.p, n, pl->max_tmax, fp));
+  HIP_TRY(launch_f0_yin(s, (const float*)pl->f0_ysig.p, d_clips, d_info, (const float*)pl->f0_energy.p, pl->f0_dt, fp,
+                        (int32_t*)pl->f0_cnt.p, (double*)pl->f0_vp.p, (int16_t*)pl->f0_bin.p, (double*)pl->f0_prob.p,
+                        n, pl->max_tmax));
+  HIP_TRY(launch_f0_viterbi(s, d_clips, d_info, pl->f0_dt, fp, (const int32_t*)pl->f0_cnt.p, (const double*)pl->f0_vp.p,
+                            (const int16_t*)pl->f0_bin.p, (const double*)pl->f0_prob.p, (uint16_t*)pl->f0_ptr.p,
+                            (uint16_t*)pl->f0_states.p, (double*)pl->f0_stats.p, d_f0, (const int64_t*)pl->f0_offs.p, n));
+  std::vector<ClipInfo> h_info(n);
+  HIP_TRY(hipMemcpyAsync(out_stats, pl->f0_stats.p, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_info.data(), d_info, n * sizeof(ClipInfo), hipMemcpyDeviceToHost, s));
+  if (out_f0 && f0_count) HIP_TRY(hipMemcpyAsync(out_f0, d_f0, f0_count * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i) out_status[i] = h_info[i].nonfinite ? AFX_CLIP_NONFINITE : AFX_CLIP_OK;
+  return AFX_OK;
+}
+
+extern "C" int afx_f0_batch(afx_plan* pl, const void* samples, int sample_fmt, int mem_kind,
+                            const int64_t* offsets, const int64_t* lengths, int n_clips, int flags,
+                            double fmin, double fmax, double* out_f0stats, int32_t* out_status,
+                            double* out_f0, const int64_t* f0_offsets) {
+  if (!pl || !offsets || !lengths || !out_f0stats || !out_status || n_clips < 0 || (!samples && n_clips > 0)) {
+    set_error("afx_f0_batch: null/invalid argument");
+    return AFX_ERR_INVALID;
+  }
+  if (sample_fmt != AFX_FMT_F32 && sample_fmt != AFX_FMT_S16) { set_error("unknown sample format"); return AFX_ERR_INVALID; }
+  if (mem_kind != AFX_MEM_HOST && mem_kind != AFX_MEM_DEVICE) { set_error("unknown mem_kind"); return AFX_ERR_INVALID; }
+  if (n_clips == 0) return AFX_OK;
+  HIP_TRY(hipSetDevice(pl->ctx->device));
+  int rc;
+  if ((rc = f0_setup(pl, fmin, fmax)) != AFX_OK) return rc;
+  const void* d_samples = samples;
+  if (mem_kind == AFX_MEM_HOST) {
+    const size_t esz = sample_fmt == AFX_FMT_S16 ? 2 : 4;
+    int64_t hi = 0;
+    for (int i = 0; i < n_clips; ++i) hi = std::max(hi, offsets[i] + lengths[i]);
+    if ((rc = ensure(pl->f0_in, (size_t)hi * esz + 16)) != AFX_OK) return rc;
+    if (hi > 0) HIP_TRY(hipMemcpyAsync(pl->f0_in.p, samples, (size_t)hi * esz, hipMemcpyHostToDevice, pl->ctx->stream));
+    d_samples = pl->f0_in.p;
+  }
+  // the stage keeps ~6 KB of workspace per frame (back-pointers, candidates, energies): bound it per chunk
+  const int64_t kMaxFrames = 160 * 1024;
+  int c0 = 0;
+  while (c0 < n_clips) {
+    int n = 0;
+    int64_t fr = 0;
+    while (c0 + n < n_clips && n < 32768) {
+      const int64_t t = 1 + lengths[c0 + n] / pl->p.hop + kFramesPerBlock;
+      if (n > 0 && fr + t > kMaxFrames) break;
+      fr += t; ++n;
+    }
+    rc = f0_chunk(pl, d_samples, sample_fmt, offsets + c0, lengths + c0, n, flags, out_f0stats + (size_t)c0 * 4,
+                  out_status + c0, out_f0, f0_offsets ? f0_offsets + c0 : nullptr);
+    if (rc != AFX_OK) return rc;
+    c0 += n;
   }
   return AFX_OK;
 }

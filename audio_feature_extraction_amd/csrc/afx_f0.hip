@@ -1,0 +1,573 @@
+// extract_f0 on MI355X: librosa.pyin at the reference's call site
+// (audio_feature_extraction_toolkit/core/feature_extractor.py:87-94) as three kernels over the
+// preprocessed signal.  Everything that decides a pitch is float64, as in the pinned numpy stack;
+// the one float32 piece -- the running frame energy, a sequential np.cumsum of a float32 array --
+// is reproduced add for add, because near a trough the difference function is smaller than its
+// rounding.
+//   k_f0_energy   one lane per frame: e[W + tau] - e[tau] of the float32 running sum of squares
+//   k_f0_yin      one wave per frame: autocorrelation (direct, float64), difference function,
+//                 cumulative-mean normalisation, troughs, threshold/Boltzmann/Beta probabilities,
+//                 parabolic refinement, pitch bins -> a sparse observation column per frame
+//   k_f0_viterbi  one workgroup per clip: log-domain Viterbi over 2 x n_bins states with the banded
+//                 transition matrix, back-tracking, f0 statistics (feature_extractor.py:97-114)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "afx_f0.h"
+
+namespace afx {
+
+#define F0_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__device__ __forceinline__ double shfl_d(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl(lo, src); hi = __shfl(hi, src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_up_d(double v, int delta) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_up(lo, delta); hi = __shfl_up(hi, delta);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_xor_d(double v, int m) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += shfl_xor_d(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmin(v, shfl_xor_d(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {       // set bits of mask below this lane
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_f0_energy: energy_frames[tau] = e[W + tau] - e[tau], e = np.cumsum(frame ** 2) in float32.
+// The chain is serial per frame, so a lane takes a frame; the block's samples sit in LDS once
+// (index padded by one word per hop so that the lanes' strided walks hit distinct banks), and the
+// tau <= max_period history of each lane in a [tau][lane] array that is overwritten by the result
+// and written out transposed (coalesced).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sq_acc(float e, float y) {
+#pragma clang fp contract(off)       // y**2 is rounded before the running sum takes it
+  const float q = y * y;
+  return e + q;
+}
+
+size_t f0_energy_lds_bytes(const F0Params& fp) {
+  const size_t span = (size_t)(fp.epb - 1) * fp.hop + fp.W + fp.n_tau;
+  return (span + span / fp.hop + 8) * 4 + (size_t)fp.n_tau * (fp.epb + 1) * 4;
+}
+
+__global__ __launch_bounds__(64) void k_f0_energy(const float* __restrict__ ysig,
+                                                  const ClipDesc* __restrict__ clips,
+                                                  const ClipInfo* __restrict__ info,
+                                                  float* __restrict__ energy, F0Params fp) {
+  extern __shared__ float sme[];
+  const int clip = blockIdx.y;
+  const ClipInfo ci = info[clip];
+  if (ci.status == AFX_CLIP_NONFINITE) return;
+  const int T = ci.T, E = fp.epb, hop = fp.hop;
+  const int t0 = blockIdx.x * E;
+  if (t0 >= T) return;
+  const ClipDesc cd = clips[clip];
+  const int64_t np = ci.end - ci.start;
+  const int lane = threadIdx.x;
+  const int span = (E - 1) * hop + fp.W + fp.n_tau;
+  float* S = sme;
+  float* H = sme + (span + span / hop + 8);
+  const int hs = E + 1;
+  const int64_t g0 = (int64_t)t0 * hop - fp.n_fft / 2;
+  const float* y = ysig + cd.off;
+  for (int i = lane; i < span; i += 64) {
+    const int64_t g = g0 + i;
+    S[i + i / hop] = (g >= 0 && g < np) ? y[g] : 0.f;
+  }
+  __syncthreads();
+  if (lane < E && t0 + lane < T) {
+    float e = 0.f;
+    const int base = lane * hop;
+    const int nsteps = fp.W + fp.n_tau;
+    for (int n = 0; n < nsteps; ++n) {
+      const int idx = base + n;
+      e = sq_acc(e, S[idx + idx / hop]);
+      if (n < fp.n_tau) H[n * hs + lane] = e;
+      if (n >= fp.W) {
+        const int tau = n - fp.W;
+        float d = e - H[tau * hs + lane];
+        if (fabsf(d) < 1e-6f) d = 0.f;
+        H[tau * hs + lane] = d;
+      }
+    }
+  }
+  __syncthreads();
+  for (int f = 0; f < E && t0 + f < T; ++f) {
+    float* row = energy + (cd.frame_base + t0 + f) * (int64_t)fp.n_tau_pad;
+    for (int tau = lane; tau < fp.n_tau; tau += 64) row[tau] = H[tau * hs + f];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_f0_yin
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxR = 16;        // lags per lane (n_tau <= 1024)
+constexpr int kMaxSlots = 16;    // trough slots per lane (n_lag <= 1024)
+
+struct YinLds { size_t span, per_wave, total; };
+__host__ __device__ inline YinLds yin_lds(const F0Params& fp) {
+  YinLds L;
+  L.span = (size_t)(kF0FramesPerBlock - 1) * fp.hop + fp.n_fft + 64;
+  // per wave (doubles): D[n_tau_pad] | X[slots*64 + 2] | CP[cap] | CB[cap] (ints, cap/2 doubles)
+  L.per_wave = (size_t)fp.n_tau_pad + (size_t)fp.slots * 64 + 2 + fp.cap + (fp.cap + 1) / 2;
+  L.total = (L.span + 4 * L.per_wave) * sizeof(double);
+  return L;
+}
+size_t f0_yin_lds_bytes(const F0Params& fp) { return yin_lds(fp).total; }
+
+__global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
+                                                const ClipDesc* __restrict__ clips,
+                                                const ClipInfo* __restrict__ info,
+                                                const float* __restrict__ energy,
+                                                F0Tables tb, F0Params fp,
+                                                int32_t* __restrict__ cand_cnt,
+                                                double* __restrict__ cand_vp,
+                                                int16_t* __restrict__ cand_bin,
+                                                double* __restrict__ cand_prob) {
+  extern __shared__ double smy[];
+  const int clip = blockIdx.y;
+  const ClipInfo ci = info[clip];
+  if (ci.status == AFX_CLIP_NONFINITE) return;
+  const int T = ci.T;
+  const int t0 = blockIdx.x * kF0FramesPerBlock;
+  if (t0 >= T) return;
+  const ClipDesc cd = clips[clip];
+  const int64_t np = ci.end - ci.start;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const YinLds L = yin_lds(fp);
+  double* Y = smy;
+  double* D = smy + L.span + (size_t)wave * L.per_wave;
+  double* X = D + fp.n_tau_pad;
+  double* CP = X + fp.slots * 64 + 2;
+  int* CB = reinterpret_cast<int*>(CP + fp.cap);
+  const int hop = fp.hop, W = fp.W, R = fp.R, slots = fp.slots, n_lag = fp.n_lag;
+
+  {
+    const int64_t g0 = (int64_t)t0 * hop - fp.n_fft / 2;
+    const float* y = ysig + cd.off;
+    for (int i = tid; i < (int)L.span; i += 256) {
+      const int64_t g = g0 + i;
+      Y[i] = (g >= 0 && g < np) ? (double)y[g] : 0.0;
+    }
+  }
+  __syncthreads();
+
+  for (int fi = 0; fi < kF0FramesPerBlock / 4; ++fi) {
+    const int f = wave * (kF0FramesPerBlock / 4) + fi;
+    const int t = t0 + f;
+    if (t >= T) break;                                   // wave-uniform
+    const int64_t slot = cd.frame_base + t;
+    const double* F = Y + (size_t)f * hop;
+
+    // ---- autocorrelation acf[tau] = sum_{i=1..W} y[i] y[i + tau]  (what irfft(rfft(y) rfft(y[W:0:-1])) [W:] is)
+    double acc[kMaxR];
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r) acc[r] = 0.0;
+    for (int i = 1; i <= W; ++i) {
+      const double yi = F[i];
+      const double* q = F + i + lane;
+#pragma unroll
+      for (int r = 0; r < kMaxR; ++r)
+        if (r < R) acc[r] = fma(yi, q[64 * r], acc[r]);
+    }
+    // ---- difference function d = (e[0] + e[tau]) [float32] - 2 acf [float64]
+    const float* Erow = energy + slot * (int64_t)fp.n_tau_pad;
+    const float e0 = Erow[0];
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r) {
+      const int tau = lane + 64 * r;
+      if (r < R && tau < fp.n_tau) {
+        double a = acc[r];
+        if (fabs(a) < 1e-6) a = 0.0;
+        const float s32 = e0 + Erow[tau];
+        D[tau] = (double)s32 - 2.0 * a;
+      }
+    }
+    F0_WAVE_SYNC();
+    // ---- cumulative mean over tau = 1 .. max_period, kept for tau >= min_period
+    {
+      const int C = (fp.max_period + 63) / 64;
+      const int lo = 1 + lane * C;
+      double s = 0.0;
+      for (int k = 0; k < C; ++k) { const int tau = lo + k; if (tau <= fp.max_period) s += D[tau]; }
+      double incl = s;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const double v = shfl_up_d(incl, o); if (lane >= o) incl += v; }
+      double run = incl - s;
+      for (int k = 0; k < C; ++k) {
+        const int tau = lo + k;
+        if (tau <= fp.max_period) {
+          run += D[tau];
+          if (tau >= fp.min_period) X[tau - fp.min_period] = D[tau] / (run / (double)tau + fp.tiny);
+        }
+      }
+    }
+    F0_WAVE_SYNC();
+    // ---- troughs (librosa.util.localmin, with the pyin rule for index 0)
+    double h[kMaxSlots], pr[kMaxSlots];
+    bool tr[kMaxSlots];
+#pragma unroll
+    for (int s = 0; s < kMaxSlots; ++s) {
+      h[s] = 0.0; pr[s] = 0.0; tr[s] = false;
+      if (s < slots) {
+        const int p = lane + 64 * s;
+        if (p < n_lag) {
+          const double x = X[p];
+          const double xm = p > 0 ? X[p - 1] : 0.0, xp = p + 1 < n_lag ? X[p + 1] : 0.0;
+          h[s] = x;
+          tr[s] = p == 0 ? (x < xp) : (p == n_lag - 1 ? (x < xm) : (x < xm && x <= xp));
+        }
+      }
+    }
+    // ---- probabilities: for every threshold, a Boltzmann prior over the troughs below it
+    int n_tr = 0;
+#pragma unroll
+    for (int s = 0; s < kMaxSlots; ++s)
+      if (s < slots) n_tr += __popcll(__ballot(tr[s]));
+    int cnt = 0;
+    double vp = 0.0;
+    if (n_tr > 0) {
+      for (int k = 1; k <= kF0Thresholds; ++k) {
+        const double thr = tb.thr[k];
+        int n = 0;
+#pragma unroll
+        for (int s = 0; s < kMaxSlots; ++s)
+          if (s < slots) n += __popcll(__ballot(tr[s] && h[s] < thr));
+        if (n == 0) continue;
+        const double fact = tb.bfact[n], bk = tb.beta[k - 1];
+        int running = 0;
+#pragma unroll
+        for (int s = 0; s < kMaxSlots; ++s) {
+          if (s < slots) {
+            const bool below = tr[s] && h[s] < thr;
+            const unsigned long long m = __ballot(below);
+            if (below) {
+              const double prior = fact * tb.bexp[running + lanes_below(m)];
+              pr[s] += prior * bk;
+            }
+            running += __popcll(m);
+          }
+        }
+      }
+      // global minimum (first occurrence) collects the mass of the thresholds it does not undercut
+      double hm = INFINITY;
+#pragma unroll
+      for (int s = 0; s < kMaxSlots; ++s)
+        if (s < slots && tr[s]) hm = fmin(hm, h[s]);
+      hm = wave_min_d(hm);
+      int pm = 1 << 30;
+#pragma unroll
+      for (int s = 0; s < kMaxSlots; ++s)
+        if (s < slots && tr[s] && h[s] == hm) pm = min(pm, lane + 64 * s);
+      pm = wave_min_i(pm);
+      int nbelow = 0;
+      for (int k0 = 1; k0 <= kF0Thresholds; k0 += 64) {
+        const int k = k0 + lane;
+        nbelow += __popcll(__ballot(k <= kF0Thresholds && !(hm < tb.thr[k <= kF0Thresholds ? k : kF0Thresholds])));
+      }
+      const double extra = fp.no_trough_prob * tb.cumbeta[nbelow];
+#pragma unroll
+      for (int s = 0; s < kMaxSlots; ++s)
+        if (s < slots && tr[s] && lane + 64 * s == pm) pr[s] += extra;
+      // ---- candidates in increasing period: refine, map to a pitch bin
+#pragma unroll
+      for (int s = 0; s < kMaxSlots; ++s) {
+        if (s < slots) {
+          const bool nz = tr[s] && pr[s] != 0.0;
+          const unsigned long long m = __ballot(nz);
+          if (nz) {
+            const int p = lane + 64 * s;
+            double shift = 0.0;
+            if (p > 0 && p < n_lag - 1) {
+              const double xm = X[p - 1], xp = X[p + 1];
+              const double a = xp + xm - 2.0 * h[s];
+              const double b = (xp - xm) / 2.0;
+              shift = fabs(b) >= fabs(a) ? 0.0 : -b / a;
+            }
+            const double period = (double)(fp.min_period + p) + shift;
+            const double f0 = fp.sr / period;
+            double bf = rint(fp.bins_per_octave * log2(f0 / fp.fmin));
+            bf = bf < 0.0 ? 0.0 : (bf > (double)fp.n_bins ? (double)fp.n_bins : bf);
+            const int j = cnt + lanes_below(m);
+            CB[j] = (int)bf;
+            CP[j] = pr[s];
+          }
+          cnt += __popcll(m);
+        }
+      }
+      F0_WAVE_SYNC();
+      // several candidates in one bin: the last (longest period) wins, as numpy's indexed assignment
+      for (int j = lane; j < cnt; j += 64) {
+        const int b = CB[j];
+        const bool keep = (j == cnt - 1) || CB[j + 1] != b;
+        if (keep && b < fp.n_bins) vp += CP[j];
+        cand_bin[slot * fp.cap + j] = (int16_t)(keep ? b : -1);
+        cand_prob[slot * fp.cap + j] = CP[j];
+      }
+      vp = wave_sum_d(vp);
+      F0_WAVE_SYNC();
+    }
+    if (lane == 0) {
+      cand_cnt[slot] = cnt;
+      cand_vp[slot] = vp < 0.0 ? 0.0 : (vp > 1.0 ? 1.0 : vp);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_f0_viterbi: librosa.sequence.viterbi on the (sparse) observation columns, then the statistics.
+// States 0 .. n_bins-1 voiced, n_bins .. 2 n_bins-1 unvoiced.  Transition kron([[.99,.01],[.01,.99]],
+// local): a source row is a triangle of half-width `band` around it, cut at the range ends and
+// normalised, so log(A + tiny) has 2 x (2 band + 1) distinct rows of (2 band + 1) entries -- held in
+// LDS -- and log(tiny) everywhere else.  Out-of-band moves therefore all cost the same: the best of them
+// is the previous column's global maximum, which is computed once per step.
+// ---------------------------------------------------------------------------------------------
+constexpr int kVitThreads = 640;
+constexpr int kVitRows = 16;          // back-pointer rows buffered in LDS
+
+struct VitLds { size_t v, olp, lt, red, pb, total; };
+__host__ __device__ inline VitLds vit_lds(const F0Params& fp) {
+  const size_t S = 2 * (size_t)fp.n_bins, width = 2 * (size_t)fp.band + 1;
+  VitLds L;
+  L.v = 0;                                   // vA, vB: 2 S doubles
+  L.olp = 2 * S;                             // n_bins doubles
+  L.lt = L.olp + fp.n_bins;                  // 2 * width * width doubles
+  L.red = L.lt + 2 * width * width;          // 32 doubles + 32 ints (16 doubles)
+  L.pb = L.red + 48;                         // kVitRows * S uint16
+  L.total = L.pb * sizeof(double) + kVitRows * S * sizeof(uint16_t) + 16;
+  return L;
+}
+size_t f0_viterbi_lds_bytes(const F0Params& fp) { return vit_lds(fp).total; }
+
+__global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __restrict__ clips,
+                                                            const ClipInfo* __restrict__ info,
+                                                            F0Tables tb, F0Params fp,
+                                                            const int32_t* __restrict__ cand_cnt,
+                                                            const double* __restrict__ cand_vp,
+                                                            const int16_t* __restrict__ cand_bin,
+                                                            const double* __restrict__ cand_prob,
+                                                            uint16_t* __restrict__ ptr_rows,
+                                                            uint16_t* __restrict__ states,
+                                                            double* __restrict__ out_stats,
+                                                            double* __restrict__ out_f0,
+                                                            const int64_t* __restrict__ f0_offsets) {
+  extern __shared__ double smv[];
+  const int clip = blockIdx.x;
+  const ClipInfo ci = info[clip];
+  double* st = out_stats + (size_t)clip * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = kVitThreads / 64;
+  if (ci.status == AFX_CLIP_NONFINITE || ci.T < 1) {
+    if (tid == 0) { st[0] = 0.0; st[1] = 0.0; st[2] = 1.0; st[3] = 0.0; }
+    return;
+  }
+  const ClipDesc cd = clips[clip];
+  const int T = ci.T, nb = fp.n_bins, S = 2 * nb, band = fp.band, width = 2 * band + 1;
+  const VitLds L = vit_lds(fp);
+  double* vprev = smv + L.v;
+  double* vcur = vprev + S;
+  double* olp = smv + L.olp;
+  double* LT = smv + L.lt;
+  double* redv = smv + L.red;
+  int* redi = reinterpret_cast<int*>(redv + 32);
+  uint16_t* PB = reinterpret_cast<uint16_t*>(smv + L.pb);
+  const double c0 = fp.c0;
+
+  for (int i = tid; i < 2 * width * width; i += kVitThreads) LT[i] = tb.lt[i];
+  const double lpi_u = log(1.0 / (double)nb + fp.tiny);
+
+  // block-wide (max value, lowest index) of v[0..S)
+  auto block_argmax = [&](const double* v, double& gmax, int& garg) {
+    double bv = -INFINITY; int bi = 1 << 30;
+    for (int j = tid; j < S; j += kVitThreads) { const double x = v[j]; if (x > bv) { bv = x; bi = j; } }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const double ov = shfl_xor_d(bv, o); const int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
+    __syncthreads();
+    gmax = redv[0]; garg = redi[0];
+    for (int w = 1; w < NW; ++w) {
+      const double ov = redv[w]; const int oi = redi[w];
+      if (ov > gmax || (ov == gmax && oi < garg)) { gmax = ov; garg = oi; }
+    }
+    __syncthreads();
+  };
+
+  for (int t = 0; t < T; ++t) {
+    const int64_t slot = cd.frame_base + t;
+    // ---- log observation column: voiced bins from the candidate list, one value for every unvoiced bin
+    for (int b = tid; b < nb; b += kVitThreads) olp[b] = c0;
+    __syncthreads();
+    const int cnt = cand_cnt[slot];
+    for (int j = tid; j < cnt; j += kVitThreads) {
+      const int b = cand_bin[slot * fp.cap + j];
+      if (b >= 0 && b < nb) olp[b] = log(cand_prob[slot * fp.cap + j] + fp.tiny);
+    }
+    const double lu = log((1.0 - cand_vp[slot]) / (double)nb + fp.tiny);
+    __syncthreads();
+    if (t == 0) {
+      for (int j = tid; j < S; j += kVitThreads) vcur[j] = j < nb ? olp[j] + c0 : lu + lpi_u;
+    } else {
+      double gmax; int garg;
+      block_argmax(vprev, gmax, garg);
+      const int gb = garg >= nb ? garg - nb : garg;
+      for (int j = tid; j < S; j += kVitThreads) {
+        const int jv = j >= nb ? 1 : 0, jb = j - jv * nb;
+        const int blo = jb - band < 0 ? 0 : jb - band, bhi = jb + band > nb - 1 ? nb - 1 : jb + band;
+        double best = -INFINITY; int bk = 0;
+        for (int sv = 0; sv < 2; ++sv) {
+          const double* ltab = LT + (size_t)(sv == jv ? 0 : 1) * width * width;
+          const double* vp = vprev + sv * nb;
+          for (int b = blo; b <= bhi; ++b) {
+            const int rc = b < band ? 1 + b : (b > nb - 1 - band ? 1 + band + (nb - 1 - b) : 0);
+            const double cand = vp[b] + ltab[rc * width + (jb - b + band)];
+            if (cand > best) { best = cand; bk = sv * nb + b; }
+          }
+        }
+        if (gb < blo || gb > bhi) {                      // the best out-of-band source
+          const double cand = gmax + c0;
+          if (cand > best || (cand == best && garg < bk)) { best = cand; bk = garg; }
+        }
+        vcur[j] = (jv ? lu : olp[jb]) + best;
+        PB[(t % kVitRows) * S + j] = (uint16_t)bk;
+      }
+    }
+    __syncthreads();
+    if (t > 0 && ((t % kVitRows) == kVitRows - 1 || t == T - 1)) {
+      const int r0 = t - (t % kVitRows);
+      const int nrows = t - r0 + 1;
+      uint16_t* dst = ptr_rows + (cd.frame_base + r0) * (int64_t)S;
+      for (int i = tid; i < nrows * S; i += kVitThreads) dst[i] = PB[i];
+    }
+    double* tmp = vprev; vprev = vcur; vcur = tmp;
+    __syncthreads();
+  }
+  // ---- last state, back-tracking through the stored rows (a block of rows at a time through LDS)
+  double gmax; int garg;
+  block_argmax(vprev, gmax, garg);
+  uint16_t* sts = states + cd.frame_base;
+  int cur = garg;
+  if (tid == 0) sts[T - 1] = (uint16_t)cur;
+  for (int r0 = ((T - 1) / kVitRows) * kVitRows; r0 >= 0; r0 -= kVitRows) {
+    const int r1 = r0 + kVitRows - 1 < T - 1 ? r0 + kVitRows - 1 : T - 1;       // rows r0..r1 (row t maps state at t -> t-1)
+    const int nrows = r1 - r0 + 1;
+    const uint16_t* src = ptr_rows + (cd.frame_base + r0) * (int64_t)S;
+    for (int i = tid; i < nrows * S; i += kVitThreads) PB[i] = src[i];
+    __syncthreads();
+    if (tid == 0) {
+      for (int t = r1; t >= r0 && t >= 1; --t) {
+        cur = PB[(t - r0) * S + cur];
+        sts[t - 1] = (uint16_t)cur;
+      }
+    }
+    __syncthreads();
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- statistics over voiced frames (feature_extractor.py:97-107)
+  auto block_sum = [&](double v) -> double {
+    v = wave_sum_d(v);
+    if (lane == 0) redv[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < NW; ++w) s += redv[w];
+    __syncthreads();
+    return s;
+  };
+  double s1 = 0.0, c1 = 0.0;
+  for (int t = tid; t < T; t += kVitThreads) {
+    const int q = sts[t];
+    const bool voiced = q < nb;
+    const double f = tb.freqs[voiced ? q : q - nb];
+    if (voiced) { s1 += f; c1 += 1.0; }
+    if (out_f0) out_f0[f0_offsets[clip] + t] = voiced ? f : (double)NAN;
+  }
+  const double cntv = block_sum(c1);
+  const double sum = block_sum(s1);
+  if (cntv > 0.0) {
+    const double mean = sum / cntv;
+    double s2 = 0.0;
+    for (int t = tid; t < T; t += kVitThreads) {
+      const int q = sts[t];
+      if (q < nb) { const double d = tb.freqs[q] - mean; s2 += d * d; }
+    }
+    const double var = block_sum(s2) / cntv;
+    if (tid == 0) {
+      const double missing = ((double)T - cntv) / (double)T;
+      st[0] = mean; st[1] = sqrt(var); st[2] = missing; st[3] = 1.0 - missing;
+    }
+  } else if (tid == 0) {
+    st[0] = 0.0; st[1] = 0.0; st[2] = 1.0; st[3] = 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t launch_f0_energy(hipStream_t s, const float* ysig, const ClipDesc* clips, const ClipInfo* info,
+                            float* energy, int n_clips, int max_tmax, const F0Params& fp) {
+  const size_t lds = f0_energy_lds_bytes(fp);
+  hipError_t e = allow_lds(k_f0_energy, lds);
+  if (e != hipSuccess) return e;
+  dim3 grid((max_tmax + fp.epb - 1) / fp.epb, n_clips);
+  hipLaunchKernelGGL(k_f0_energy, grid, dim3(64), lds, s, ysig, clips, info, energy, fp);
+  return hipGetLastError();
+}
+
+hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips, const ClipInfo* info,
+                         const float* energy, const F0Tables& tb, const F0Params& fp,
+                         int32_t* cand_cnt, double* cand_vp, int16_t* cand_bin, double* cand_prob,
+                         int n_clips, int max_tmax) {
+  const size_t lds = f0_yin_lds_bytes(fp);
+  hipError_t e = allow_lds(k_f0_yin, lds);
+  if (e != hipSuccess) return e;
+  dim3 grid((max_tmax + kF0FramesPerBlock - 1) / kF0FramesPerBlock, n_clips);
+  hipLaunchKernelGGL(k_f0_yin, grid, dim3(256), lds, s, ysig, clips, info, energy, tb, fp, cand_cnt, cand_vp,
+                     cand_bin, cand_prob);
+  return hipGetLastError();
+}
+
+hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const F0Tables& tb,
+                             const F0Params& fp, const int32_t* cand_cnt, const double* cand_vp,
+                             const int16_t* cand_bin, const double* cand_prob, uint16_t* ptr_rows,
+                             uint16_t* states, double* out_stats, double* out_f0, const int64_t* f0_offsets,
+                             int n_clips) {
+  const size_t lds = f0_viterbi_lds_bytes(fp);
+  hipError_t e = allow_lds(k_f0_viterbi, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_f0_viterbi, dim3(n_clips), dim3(kVitThreads), lds, s, clips, info, tb, fp, cand_cnt,
+                     cand_vp, cand_bin, cand_prob, ptr_rows, states, out_stats, out_f0, f0_offsets);
+  return hipGetLastError();
+}
+
+}  // namespace afx

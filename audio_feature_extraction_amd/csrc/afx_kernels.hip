@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "afx_device.h"
+#include "afx_f0.h"
 
 namespace afx {
 
@@ -1710,6 +1711,29 @@ __global__ __launch_bounds__(256) void k_preemph(const float* __restrict__ y, fl
   out[i] = (i == 0) ? ((n > 1) ? preemph0(y[0], y[1]) : y[0]) : preemph1(y[i], y[i - 1], b1);
 }
 
+// extract_f0 staging: the preprocessed signal itself (pre-emphasised, trimmed span moved to the clip's
+// offset) as float32 -- what the reference hands to librosa.pyin (feature_extractor.py:195).
+__global__ __launch_bounds__(256) void k_f0_prep(const void* __restrict__ samples,
+                                                 const ClipDesc* __restrict__ clips,
+                                                 const ClipInfo* __restrict__ info,
+                                                 float* __restrict__ ysig, KParams kp) {
+  const int clip = blockIdx.y;
+  const ClipInfo ci = info[clip];
+  const ClipDesc cd = clips[clip];
+  const int64_t np = ci.end - ci.start;
+  const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < np; n += (int64_t)gridDim.x * 256) {
+    const int64_t i = ci.start + n;
+    const float y = ld_sample(samples, kp.fmt, cd.off + i);
+    float v = y;
+    if (pre) {
+      if (i == 0) v = (cd.len > 1) ? preemph0(y, ld_sample(samples, kp.fmt, cd.off + 1)) : y;
+      else v = preemph1(y, ld_sample(samples, kp.fmt, cd.off + i - 1), kp.preemph_b1);
+    }
+    ysig[cd.off + n] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -1830,6 +1854,13 @@ hipError_t launch_stats(hipStream_t s, const ClipDesc* clips, const ClipInfo* in
 
 hipError_t launch_preemph(hipStream_t s, const float* y, float* out, int64_t n, float b1) {
   hipLaunchKernelGGL(k_preemph, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, out, n, b1);
+  return hipGetLastError();
+}
+
+hipError_t launch_f0_prep(hipStream_t s, const void* samples, const ClipDesc* clips, const ClipInfo* info,
+                          float* ysig, int n_clips, int64_t max_len, const KParams& kp) {
+  const int gx = (int)std::min<int64_t>(std::max<int64_t>((max_len + 255) / 256, 1), 1024);
+  hipLaunchKernelGGL(k_f0_prep, dim3(gx, n_clips), dim3(256), 0, s, samples, clips, info, ysig, kp);
   return hipGetLastError();
 }
 

@@ -137,6 +137,23 @@ int afx_extract_batch(afx_plan* plan,
                       int64_t* out_trim, int32_t* out_nframes,
                       float* out_frames, const int64_t* frame_offsets);
 
+/* extract_f0 (F:76-114): librosa.pyin(y, fmin, fmax, frame_length=n_fft, hop_length=hop, sr)
+ * at librosa's defaults, of the same preprocessed clips (flags as for
+ * afx_extract_batch: the reference feeds y_processed, F:195), reduced as F:97-107.
+ *   out_f0stats host double[4 * n_clips]: f0_mean, f0_std, f0_missing_rate, f0_quality
+ *             (0, 0, 1, 0 when no frame is voiced -- the reference's own branch F:103-107)
+ *   out_status host int32[n_clips]: AFX_CLIP_OK or AFX_CLIP_NONFINITE
+ *   out_f0    NULL, or host double buffer: clip i's per-frame f0 (NaN = unvoiced) in
+ *             out_f0[f0_offsets[i] .. + T_i), T_i = 1 + kept_length_i / hop
+ * Float64 throughout, except the running frame energy, which numpy accumulates in
+ * float32 and which is reproduced add for add. */
+int afx_f0_batch(afx_plan* plan,
+                 const void* samples, int sample_fmt, int mem_kind,
+                 const int64_t* offsets, const int64_t* lengths, int n_clips,
+                 int flags, double fmin, double fmax,
+                 double* out_f0stats, int32_t* out_status,
+                 double* out_f0, const int64_t* f0_offsets);
+
 /* preprocess_audio(y) (F:58-74): pre-emphasis + trim of ONE host clip.
  * out_y receives the n pre-emphasised samples (host, n floats); the kept span
  * is out_y[*start .. *end). */

@@ -1,0 +1,90 @@
+"""extract_f0 on the GPU (afx_f0_batch) against the pYIN oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+from audio_feature_extraction_amd import _native as N
+from audio_feature_extraction_amd.synth import make_clip
+from oracle import cpu_ref as R
+from oracle import pyin_ref as P
+
+pytestmark = pytest.mark.gpu
+
+SR = 22050
+
+
+@pytest.fixture(scope="module")
+def plan():
+    ctx = N.Context(0)
+    pl = N.Plan(ctx, N.make_params(SR, 1024, 256, 13))
+    yield pl
+    pl.close()
+    ctx.close()
+
+
+def run(plan, clips, flags):
+    lengths = np.array([c.size for c in clips], np.int64)
+    pad = (lengths + 3) // 4 * 4
+    offsets = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.int64)
+    buf = np.zeros(int(pad.sum()), np.float32)
+    for c, o in zip(clips, offsets):
+        buf[o:o + c.size] = c
+    out = plan.f0_batch(buf, offsets, lengths, P.C2_HZ, P.C7_HZ, flags=flags, want_frames=True)
+    f0 = [out["f0_flat"][o:o + 1 + n // 256] for o, n in zip(out["f0_offsets"], lengths)]
+    return out, f0
+
+
+def voiced_tone(freq, seconds, vib=0.0, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(int(SR * seconds)) / SR
+    f = freq * (1 + vib * np.sin(2 * np.pi * 5 * t))
+    ph = 2 * np.pi * np.cumsum(f) / SR
+    y = 0.3 * np.sin(ph) + 0.1 * np.sin(2 * ph + 0.3) + 0.05 * np.sin(3 * ph + 1.0)
+    y += 0.005 * rng.standard_normal(t.size)
+    return y.astype(np.float32)
+
+
+def check_clip(f0_gpu, stats_gpu, y_processed, tag):
+    f0_ref, voiced_ref, _ = P.pyin(y_processed, sr=SR, frame_length=1024, hop_length=256)
+    assert f0_gpu.shape == f0_ref.shape, tag
+    same = (np.isnan(f0_gpu) == np.isnan(f0_ref))
+    v = ~np.isnan(f0_ref) & ~np.isnan(f0_gpu)
+    same[v] &= np.abs(f0_gpu[v] - f0_ref[v]) <= 1e-9 * f0_ref[v]
+    # the decoded path must be the oracle's; allow isolated frames for near-ties in float64 log/argmax
+    assert same.mean() >= 0.99, (tag, same.mean(), np.flatnonzero(~same)[:10])
+    ref = P.extract_f0(y_processed, sr=SR, frame_length=1024, hop_length=256)
+    if same.all():
+        np.testing.assert_allclose(stats_gpu, [ref["f0_mean"], ref["f0_std"], ref["f0_missing_rate"], ref["f0_quality"]],
+                                   rtol=1e-10, atol=1e-12, err_msg=tag)
+    else:
+        assert abs(stats_gpu[0] - ref["f0_mean"]) <= 5e-3 * max(ref["f0_mean"], 1.0), tag
+        assert abs(stats_gpu[2] - ref["f0_missing_rate"]) <= 0.02, tag
+
+
+def test_f0_of_preprocessed_signals_matches_oracle(plan):
+    clips = [voiced_tone(220.0, 0.8), voiced_tone(147.0, 1.1, vib=0.02, seed=1), voiced_tone(523.25, 0.5, vib=0.01, seed=2),
+             make_clip(3, SR, 0.7), np.zeros(3000, np.float32)]
+    out, f0 = run(plan, clips, flags=0)
+    assert out["status"].tolist() == [0] * len(clips)
+    for i, c in enumerate(clips):
+        check_clip(f0[i], out["stats"][i], c, f"staged{i}")
+    assert out["stats"][4].tolist() == [0.0, 0.0, 1.0, 0.0]
+
+
+def test_f0_fused_with_preemphasis_and_trim(plan):
+    sil = np.zeros(int(0.25 * SR), np.float32)
+    clips = [np.concatenate([sil, voiced_tone(196.0, 0.9, vib=0.015, seed=4), sil]),
+             make_clip(12, SR, 1.0, speechy=True)]
+    out, f0 = run(plan, clips, flags=N.FLAG_PREEMPH | N.FLAG_TRIM)
+    for i, c in enumerate(clips):
+        yp, _ = R.preprocess_audio(c)
+        check_clip(f0[i][:1 + yp.size // 256], out["stats"][i], yp, f"fused{i}")
+
+
+def test_f0_flags_nonfinite_and_short_clips(plan):
+    bad = voiced_tone(200.0, 0.3).copy()
+    bad[100] = np.inf
+    clips = [bad, voiced_tone(300.0, 0.02), np.array([0.1], np.float32)]
+    out, f0 = run(plan, clips, flags=0)
+    assert out["status"].tolist() == [N.CLIP_NONFINITE, 0, 0]
+    check_clip(f0[1], out["stats"][1], clips[1], "short")
+    check_clip(f0[2], out["stats"][2], clips[2], "one-sample")
