@@ -147,16 +147,32 @@ class AudioFeatureExtractor:
             raise _status_error(status, "preprocess_audio")
         return y_pre[start:end]
 
-    def extract_f0(self, y: np.ndarray) -> Dict[str, Any]:
-        """提取基頻特徵.  pYIN (feature_extractor.py:87) is not on the MFCC hot path and is not
-        built yet.  Until it is, this returns exactly the
-        reference's own no-voiced-frames branch (feature_extractor.py:103-107)."""
+    @staticmethod
+    def _f0_to_dict(s: np.ndarray) -> Dict[str, Any]:
         return {
-            "f0_mean": float(0),
-            "f0_std": float(0),
-            "f0_missing_rate": float(1),
-            "f0_quality": float(0),
+            "f0_mean": float(s[0]),
+            "f0_std": float(s[1]),
+            "f0_missing_rate": float(s[2]),
+            "f0_quality": float(s[3]),
         }
+
+    def _f0_on_gpu(self) -> bool:
+        """The batched path may compute F0 on the device only while ``extract_f0`` is the stock method."""
+        return "extract_f0" not in self.__dict__ and type(self).extract_f0 is AudioFeatureExtractor.extract_f0
+
+    def _run_f0(self, y: np.ndarray, flags: int) -> np.ndarray:
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        out = self._plan().f0_batch(y, np.zeros(1, np.int64), np.array([y.size], np.int64),
+                                    float(self.f0_min), float(self.f0_max), flags=flags)
+        if out["status"][0] != _native.CLIP_OK:
+            raise _status_error(int(out["status"][0]), "extract_f0")
+        return out["stats"][0]
+
+    def extract_f0(self, y: np.ndarray) -> Dict[str, Any]:
+        """提取基頻特徵 (feature_extractor.py:76-114): ``librosa.pyin(y, fmin=f0_min, fmax=f0_max,
+        frame_length, hop_length, sr)`` on the GPU -- difference function, probabilistic thresholds,
+        Viterbi -- reduced to mean / std over the voiced frames, missing rate and quality."""
+        return self._f0_to_dict(self._run_f0(y, 0))
 
     def extract_mfcc(self, y: np.ndarray) -> Dict[str, Any]:
         """提取MFCC特徵 of an already preprocessed signal (feature_extractor.py:116-151)."""
@@ -173,7 +189,7 @@ class AudioFeatureExtractor:
             if self._uses_reference_stages():
                 # fused: pre-emphasis + trim + MFCC + RMS in one pass over the samples
                 stats = self._run_one(y, _native.FLAG_PREEMPH | _native.FLAG_TRIM)
-                f0_features = self.extract_f0(y)
+                f0_features = self._f0_to_dict(self._run_f0(y, _native.FLAG_PREEMPH | _native.FLAG_TRIM))
                 mfcc_features, energy_features = self._stats_to_dicts(stats)
             else:
                 y_processed = self.preprocess_audio(y)

@@ -112,6 +112,8 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
     stats = np.zeros((n, 4 * K + 3), np.float32)
     status = np.full(n, -1, np.int32)
     nframes = np.zeros(n, np.int32)
+    f0s = np.zeros((n, 4), np.float64)
+    want_f0 = getattr(extractor, "_f0_on_gpu", lambda: False)()
     parts = lpt_partition([decoded[i][1].size for i in ok], len(devices))
     flags = _native.FLAG_PREEMPH | _native.FLAG_TRIM
 
@@ -128,10 +130,18 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
                         end += 1
                     chunk = sel[pos:end]
                     buf, offs, lens = _pack([decoded[i][1] for i in chunk], dt)
-                    out = plan.extract_batch(buf, offs, lens, flags=flags, fmt=fmt)
-                    stats[chunk] = out["stats"]
-                    status[chunk] = out["status"]
-                    nframes[chunk] = out["nframes"]
+                    dbuf = _native.DeviceBuffer(plan.ctx, max(buf.nbytes, 16))       # one PCIe copy for both passes
+                    try:
+                        dbuf.upload(buf)
+                        out = plan.extract_batch(dbuf, offs, lens, flags=flags, fmt=fmt)
+                        stats[chunk] = out["stats"]
+                        status[chunk] = out["status"]
+                        nframes[chunk] = out["nframes"]
+                        if want_f0:
+                            f0 = plan.f0_batch(dbuf, offs, lens, extractor.f0_min, extractor.f0_max, flags=flags, fmt=fmt)
+                            f0s[chunk] = f0["stats"]
+                    finally:
+                        dbuf.free()
                     pos = end
         except Exception as e:          # a device-level failure drops that shard's files
             for j in idxs:
@@ -156,6 +166,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
             log.error(f"處理文件 {name} 失敗: {str(err)}")
             continue
         mfcc, energy = extractor._stats_to_dicts(stats[i])
-        results.append({"file_path": str(f), **extractor.extract_f0(None), **mfcc, **energy})
+        f0d = extractor._f0_to_dict(f0s[i]) if want_f0 else extractor.extract_f0(decoded[i][1])
+        results.append({"file_path": str(f), **f0d, **mfcc, **energy})
         log.info(f"成功處理文件: {name}")
     return results

@@ -40,11 +40,15 @@ def test_override_detection_gates_fused_path():
     assert not Sub()._uses_reference_stages()
 
 
-def test_f0_stand_in_is_the_reference_unvoiced_branch():
-    out = AudioFeatureExtractor().extract_f0(np.zeros(100, np.float32))
-    assert list(out) == ["f0_mean", "f0_std", "f0_missing_rate", "f0_quality"]
-    assert out == {"f0_mean": 0.0, "f0_std": 0.0, "f0_missing_rate": 1.0, "f0_quality": 0.0}
+def test_f0_dict_schema_and_override_detection():
+    out = AudioFeatureExtractor._f0_to_dict(np.array([220.0, 1.5, 0.25, 0.75]))
+    assert list(out) == ["f0_mean", "f0_std", "f0_missing_rate", "f0_quality"]      # feature_extractor.py:109-114
+    assert out == {"f0_mean": 220.0, "f0_std": 1.5, "f0_missing_rate": 0.25, "f0_quality": 0.75}
     assert all(type(v) is float for v in out.values())
+    ex = AudioFeatureExtractor()
+    assert ex._f0_on_gpu()
+    ex.extract_f0 = lambda y: {"f0_mean": 1.0, "f0_std": 0.0, "f0_missing_rate": 0.0, "f0_quality": 1.0}
+    assert not ex._f0_on_gpu() and not ex._uses_reference_stages()
 
 
 def test_batch_process_empty_dir_returns_empty_list(tmp_path):

@@ -28,6 +28,14 @@ def _check_dict(d, y_decoded, path):
     assert all(type(d[k]) is list and len(d[k]) == 13 and type(d[k][0]) is float for k in KEYS[5:9])
     json.dumps(d)
     check_stats(_stats_vec(d), oracle_stats(y_decoded, 22050, 1024, 256, 13), 13, os.path.basename(path))
+    # f0 keys: pYIN of the preprocessed signal (feature_extractor.py:195), against the oracle
+    from oracle import cpu_ref as R
+    from oracle import pyin_ref as P
+    ref = P.extract_f0(R.preprocess_audio(y_decoded)[0], 22050, 1024, 256)
+    assert abs(d["f0_missing_rate"] - ref["f0_missing_rate"]) <= 0.02
+    assert abs(d["f0_quality"] + d["f0_missing_rate"] - 1.0) < 1e-12
+    assert abs(d["f0_mean"] - ref["f0_mean"]) <= 5e-3 * max(ref["f0_mean"], 1.0)
+    assert abs(d["f0_std"] - ref["f0_std"]) <= 5e-3 * max(ref["f0_mean"], 1.0)
 
 
 def test_extract_features_on_wav_config1(tmp_path):
