@@ -585,7 +585,8 @@ extern "C" int afx_f0_batch(afx_plan* pl, const void* samples, int sample_fmt, i
     d_samples = pl->f0_in.p;
   }
   // the stage keeps ~6 KB of workspace per frame (back-pointers, candidates, energies): bound it per chunk
-  const int64_t kMaxFrames = 160 * 1024;
+  // (7 GB; a chunk should still hold several clips per CU so that every CU runs two Viterbi workgroups)
+  const int64_t kMaxFrames = 1280 * 1024;
   int c0 = 0;
   while (c0 < n_clips) {
     int n = 0;

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <type_traits>
 
 #include "afx_f0.h"
 
@@ -126,13 +127,15 @@ __global__ __launch_bounds__(64) void k_f0_energy(const float* __restrict__ ysig
 constexpr int kMaxR = 16;        // lags per lane (n_tau <= 1024)
 constexpr int kMaxSlots = 16;    // trough slots per lane (n_lag <= 1024)
 
-struct YinLds { size_t span, per_wave, total; };
+struct YinLds { size_t span, per_wave, tables, total; };
 __host__ __device__ inline YinLds yin_lds(const F0Params& fp) {
   YinLds L;
   L.span = (size_t)(kF0FramesPerBlock - 1) * fp.hop + fp.n_fft + 64;
   // per wave (doubles): D[n_tau_pad] | X[slots*64 + 2] | CP[cap] | CB[cap] (ints, cap/2 doubles)
   L.per_wave = (size_t)fp.n_tau_pad + (size_t)fp.slots * 64 + 2 + fp.cap + (fp.cap + 1) / 2;
-  L.total = (L.span + 4 * L.per_wave) * sizeof(double);
+  // shared tables: thr[101] | beta[100] | cumbeta[101] | bfact[cap+1] | bexp[cap+1]
+  L.tables = 101 + 100 + 101 + 2 * ((size_t)fp.cap + 1);
+  L.total = (L.span + 4 * L.per_wave + L.tables) * sizeof(double);
   return L;
 }
 size_t f0_yin_lds_bytes(const F0Params& fp) { return yin_lds(fp).total; }
@@ -163,6 +166,15 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
   double* CP = X + fp.slots * 64 + 2;
   int* CB = reinterpret_cast<int*>(CP + fp.cap);
   const int hop = fp.hop, W = fp.W, R = fp.R, slots = fp.slots, n_lag = fp.n_lag;
+  // the probability tables are read inside the threshold loop with data-dependent indices: keep them in LDS
+  double* Tthr = smy + L.span + 4 * L.per_wave;
+  double* Tbeta = Tthr + 101;
+  double* Tcum = Tbeta + 100;
+  double* Tfact = Tcum + 101;
+  double* Texp = Tfact + fp.cap + 1;
+  for (int i = tid; i < 101; i += 256) { Tthr[i] = tb.thr[i]; Tcum[i] = tb.cumbeta[i]; }
+  for (int i = tid; i < 100; i += 256) Tbeta[i] = tb.beta[i];
+  for (int i = tid; i <= fp.cap; i += 256) { Tfact[i] = tb.bfact[i]; Texp[i] = tb.bexp[i]; }
 
   {
     const int64_t g0 = (int64_t)t0 * hop - fp.n_fft / 2;
@@ -185,13 +197,20 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
     double acc[kMaxR];
 #pragma unroll
     for (int r = 0; r < kMaxR; ++r) acc[r] = 0.0;
-    for (int i = 1; i <= W; ++i) {
-      const double yi = F[i];
-      const double* q = F + i + lane;
+    auto acf_loop = [&](auto RRt) {
+      constexpr int RR = decltype(RRt)::value;
+      for (int i = 1; i <= W; ++i) {
+        const double yi = F[i];
+        const double* q = F + i + lane;
 #pragma unroll
-      for (int r = 0; r < kMaxR; ++r)
-        if (r < R) acc[r] = fma(yi, q[64 * r], acc[r]);
-    }
+        for (int r = 0; r < RR; ++r) acc[r] = fma(yi, q[64 * r], acc[r]);
+      }
+    };
+    if (R <= 4) acf_loop(std::integral_constant<int, 4>());
+    else if (R <= 6) acf_loop(std::integral_constant<int, 6>());
+    else if (R <= 8) acf_loop(std::integral_constant<int, 8>());
+    else if (R <= 11) acf_loop(std::integral_constant<int, 11>());
+    else acf_loop(std::integral_constant<int, kMaxR>());
     // ---- difference function d = (e[0] + e[tau]) [float32] - 2 acf [float64]
     const float* Erow = energy + slot * (int64_t)fp.n_tau_pad;
     const float e0 = Erow[0];
@@ -250,26 +269,33 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
     double vp = 0.0;
     if (n_tr > 0) {
       for (int k = 1; k <= kF0Thresholds; ++k) {
-        const double thr = tb.thr[k];
+        const double thr = Tthr[k];
         int n = 0;
 #pragma unroll
         for (int s = 0; s < kMaxSlots; ++s)
           if (s < slots) n += __popcll(__ballot(tr[s] && h[s] < thr));
         if (n == 0) continue;
-        const double fact = tb.bfact[n], bk = tb.beta[k - 1];
+        // positions first (no memory), then one batch of table reads: a read under `if (below)` would put a
+        // dependent LDS round trip into every slot of every threshold
+        int pos[kMaxSlots];
         int running = 0;
 #pragma unroll
         for (int s = 0; s < kMaxSlots; ++s) {
+          pos[s] = -1;
           if (s < slots) {
             const bool below = tr[s] && h[s] < thr;
             const unsigned long long m = __ballot(below);
-            if (below) {
-              const double prior = fact * tb.bexp[running + lanes_below(m)];
-              pr[s] += prior * bk;
-            }
+            pos[s] = below ? running + lanes_below(m) : -1;
             running += __popcll(m);
           }
         }
+        double ex[kMaxSlots];
+#pragma unroll
+        for (int s = 0; s < kMaxSlots; ++s)
+          if (s < slots) ex[s] = Texp[pos[s] < 0 ? 0 : pos[s]];
+#pragma unroll
+        for (int s = 0; s < kMaxSlots; ++s)
+          if (s < slots && pos[s] >= 0) pr[s] += (Tfact[n] * ex[s]) * Tbeta[k - 1];
       }
       // global minimum (first occurrence) collects the mass of the thresholds it does not undercut
       double hm = INFINITY;
@@ -285,9 +311,9 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
       int nbelow = 0;
       for (int k0 = 1; k0 <= kF0Thresholds; k0 += 64) {
         const int k = k0 + lane;
-        nbelow += __popcll(__ballot(k <= kF0Thresholds && !(hm < tb.thr[k <= kF0Thresholds ? k : kF0Thresholds])));
+        nbelow += __popcll(__ballot(k <= kF0Thresholds && !(hm < Tthr[k <= kF0Thresholds ? k : kF0Thresholds])));
       }
-      const double extra = fp.no_trough_prob * tb.cumbeta[nbelow];
+      const double extra = fp.no_trough_prob * Tcum[nbelow];
 #pragma unroll
       for (int s = 0; s < kMaxSlots; ++s)
         if (s < slots && tr[s] && lane + 64 * s == pm) pr[s] += extra;
@@ -345,7 +371,8 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
 // is the previous column's global maximum, which is computed once per step.
 // ---------------------------------------------------------------------------------------------
 constexpr int kVitThreads = 640;
-constexpr int kVitRows = 16;          // back-pointer rows buffered in LDS
+constexpr int kVitRows = 4;           // back-pointer rows buffered in LDS during the forward pass
+constexpr int kVitBackRows = 16;      // rows per LDS refill while back-tracking (reuses the forward pass's arrays)
 
 struct VitLds { size_t v, olp, lt, red, pb, total; };
 __host__ __device__ inline VitLds vit_lds(const F0Params& fp) {
@@ -417,17 +444,26 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
     __syncthreads();
   };
 
+  // candidate list of the step after the current one rides in registers (one entry per thread; cap <= threads)
+  const double* LTs = LT;                               // stay, interior row class
+  const double* LTw = LT + (size_t)width * width;       // switch, interior row class
+  int pf_cnt = cand_cnt[cd.frame_base];
+  double pf_vp = cand_vp[cd.frame_base];
+  int pf_bin = -1; double pf_prob = 0.0;
+  if (tid < pf_cnt) { pf_bin = cand_bin[cd.frame_base * fp.cap + tid]; pf_prob = cand_prob[cd.frame_base * fp.cap + tid]; }
+
   for (int t = 0; t < T; ++t) {
-    const int64_t slot = cd.frame_base + t;
     // ---- log observation column: voiced bins from the candidate list, one value for every unvoiced bin
     for (int b = tid; b < nb; b += kVitThreads) olp[b] = c0;
     __syncthreads();
-    const int cnt = cand_cnt[slot];
-    for (int j = tid; j < cnt; j += kVitThreads) {
-      const int b = cand_bin[slot * fp.cap + j];
-      if (b >= 0 && b < nb) olp[b] = log(cand_prob[slot * fp.cap + j] + fp.tiny);
+    if (pf_bin >= 0 && pf_bin < nb) olp[pf_bin] = log(pf_prob + fp.tiny);
+    const double lu = log((1.0 - pf_vp) / (double)nb + fp.tiny);
+    if (t + 1 < T) {                                     // issue the next step's loads now
+      const int64_t ns = cd.frame_base + t + 1;
+      pf_cnt = cand_cnt[ns]; pf_vp = cand_vp[ns];
+      pf_bin = -1;
+      if (tid < pf_cnt) { pf_bin = cand_bin[ns * fp.cap + tid]; pf_prob = cand_prob[ns * fp.cap + tid]; }
     }
-    const double lu = log((1.0 - cand_vp[slot]) / (double)nb + fp.tiny);
     __syncthreads();
     if (t == 0) {
       for (int j = tid; j < S; j += kVitThreads) vcur[j] = j < nb ? olp[j] + c0 : lu + lpi_u;
@@ -435,25 +471,63 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
       double gmax; int garg;
       block_argmax(vprev, gmax, garg);
       const int gb = garg >= nb ? garg - nb : garg;
-      for (int j = tid; j < S; j += kVitThreads) {
-        const int jv = j >= nb ? 1 : 0, jb = j - jv * nb;
+      const double* v0 = vprev;                          // voiced sources
+      const double* v1 = vprev + nb;                     // unvoiced sources
+      // one thread per pitch bin jb: both targets (voiced jb, unvoiced jb) from one walk over the band.
+      // x_yz: best value / source bin for source voicing y -> target voicing z; sources in ascending index,
+      // strict '>' keeps the first maximum (numpy argmax).
+      for (int jb = tid; jb < nb; jb += kVitThreads) {
         const int blo = jb - band < 0 ? 0 : jb - band, bhi = jb + band > nb - 1 ? nb - 1 : jb + band;
-        double best = -INFINITY; int bk = 0;
-        for (int sv = 0; sv < 2; ++sv) {
-          const double* ltab = LT + (size_t)(sv == jv ? 0 : 1) * width * width;
-          const double* vp = vprev + sv * nb;
-          for (int b = blo; b <= bhi; ++b) {
-            const int rc = b < band ? 1 + b : (b > nb - 1 - band ? 1 + band + (nb - 1 - b) : 0);
-            const double cand = vp[b] + ltab[rc * width + (jb - b + band)];
-            if (cand > best) { best = cand; bk = sv * nb + b; }
+        double m00 = -INFINITY, m01 = -INFINITY, m10 = -INFINITY, m11 = -INFINITY;
+        int i00 = 0, i01 = 0, i10 = 0, i11 = 0;
+        auto upd = [](double c, int b, double& m, int& i) { const bool g = c > m; m = fmax(m, c); i = g ? b : i; };
+        // log-transition entry of source b -> target jb is LT[rc(b)][jb - b + band]; rc = 0 for interior sources,
+        // 1 + b below `band`, 1 + band + (nb - 1 - b) within `band` of the top: three runs of b, each with a
+        // constant table stride
+        auto scan = [&](int b0, int b1, int idx0, int stride) {
+          const double* ps = LTs + idx0;
+          const double* pw = LTw + idx0;
+          for (int b = b0; b <= b1; ++b) {
+            const double a0 = v0[b], a1 = v1[b];
+            const double ws = *ps, ww = *pw;
+            ps += stride; pw += stride;
+            upd(a0 + ws, b, m00, i00); upd(a0 + ww, b, m01, i01);
+            upd(a1 + ww, b, m10, i10); upd(a1 + ws, b, m11, i11);
           }
+        };
+        if (jb >= 2 * band && jb <= nb - 1 - 2 * band) {  // every source row is an interior row
+          const double* p0 = v0 + (jb - band);
+          const double* p1 = v1 + (jb - band);
+#pragma unroll 3
+          for (int e = 0; e < width; ++e) {
+            const double a0 = p0[e], a1 = p1[e];
+            const double ws = LTs[2 * band - e], ww = LTw[2 * band - e];
+            const int b = jb - band + e;
+            upd(a0 + ws, b, m00, i00); upd(a0 + ww, b, m01, i01);
+            upd(a1 + ww, b, m10, i10); upd(a1 + ws, b, m11, i11);
+          }
+        } else {
+          const int lo_end = bhi < band - 1 ? bhi : band - 1;                    // sources with rc = 1 + b
+          if (blo <= lo_end) scan(blo, lo_end, (1 + blo) * width + (jb - blo + band), width - 1);
+          const int mid0 = blo > band ? blo : band, mid1 = bhi < nb - 1 - band ? bhi : nb - 1 - band;
+          if (mid0 <= mid1) scan(mid0, mid1, jb - mid0 + band, -1);
+          const int hi0 = blo > nb - band ? blo : nb - band;                     // sources with rc = 1 + band + (nb - 1 - b)
+          if (hi0 <= bhi) scan(hi0, bhi, (1 + band + (nb - 1 - hi0)) * width + (jb - hi0 + band), -(width + 1));
         }
+        // target voiced: voiced sources first (lower index), then unvoiced; target unvoiced likewise
+        double bv = m00; int kv = i00;
+        if (m10 > bv) { bv = m10; kv = nb + i10; }
+        double bu = m01; int ku = i01;
+        if (m11 > bu) { bu = m11; ku = nb + i11; }
         if (gb < blo || gb > bhi) {                      // the best out-of-band source
           const double cand = gmax + c0;
-          if (cand > best || (cand == best && garg < bk)) { best = cand; bk = garg; }
+          if (cand > bv || (cand == bv && garg < kv)) { bv = cand; kv = garg; }
+          if (cand > bu || (cand == bu && garg < ku)) { bu = cand; ku = garg; }
         }
-        vcur[j] = (jv ? lu : olp[jb]) + best;
-        PB[(t % kVitRows) * S + j] = (uint16_t)bk;
+        vcur[jb] = olp[jb] + bv;
+        vcur[nb + jb] = lu + bu;
+        PB[(t % kVitRows) * S + jb] = (uint16_t)kv;
+        PB[(t % kVitRows) * S + nb + jb] = (uint16_t)ku;
       }
     }
     __syncthreads();
@@ -472,15 +546,16 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
   uint16_t* sts = states + cd.frame_base;
   int cur = garg;
   if (tid == 0) sts[T - 1] = (uint16_t)cur;
-  for (int r0 = ((T - 1) / kVitRows) * kVitRows; r0 >= 0; r0 -= kVitRows) {
-    const int r1 = r0 + kVitRows - 1 < T - 1 ? r0 + kVitRows - 1 : T - 1;       // rows r0..r1 (row t maps state at t -> t-1)
+  uint16_t* BB = reinterpret_cast<uint16_t*>(smv);       // value / observation / transition arrays are dead now
+  for (int r0 = ((T - 1) / kVitBackRows) * kVitBackRows; r0 >= 0; r0 -= kVitBackRows) {
+    const int r1 = r0 + kVitBackRows - 1 < T - 1 ? r0 + kVitBackRows - 1 : T - 1;   // row t maps the state at t to t-1
     const int nrows = r1 - r0 + 1;
     const uint16_t* src = ptr_rows + (cd.frame_base + r0) * (int64_t)S;
-    for (int i = tid; i < nrows * S; i += kVitThreads) PB[i] = src[i];
+    for (int i = tid; i < nrows * S; i += kVitThreads) BB[i] = src[i];
     __syncthreads();
     if (tid == 0) {
       for (int t = r1; t >= r0 && t >= 1; --t) {
-        cur = PB[(t - r0) * S + cur];
+        cur = BB[(t - r0) * S + cur];
         sts[t - 1] = (uint16_t)cur;
       }
     }

@@ -14,7 +14,7 @@ for idx in (0,1,2):
     same=(np.isnan(f0)==np.isnan(r)); v=~np.isnan(f0)&~np.isnan(r); same[v]&=np.abs(f0[v]-r[v])<=1e-9*r[v]
     print('clip',idx,'frames',len(r),'match',same.mean(),'voiced ref',(~np.isnan(r)).mean(),'stats',out['stats'][0], P.extract_f0(y))
 # throughput
-n=200
+n=1000
 samples,offsets,lengths=make_batch(n,SR,10.0,workers=16)
 d=N.DeviceBuffer(ctx,samples.nbytes); d.upload(samples)
 plan.f0_batch(d,offsets,lengths,P.C2_HZ,P.C7_HZ)
