@@ -26,7 +26,7 @@ SYMBOLS = (
     "afx_version", "afx_device_count", "afx_last_error", "afx_init", "afx_destroy",
     "afx_malloc", "afx_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
     "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables",
-    "afx_extract_batch", "afx_f0_batch", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings",
+    "afx_extract_batch", "afx_f0_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings",
 )
 
 
@@ -78,11 +78,25 @@ def lib() -> C.CDLL:
         L.afx_build_tables.argtypes = [C.POINTER(Params), vp, vp, vp]
         L.afx_extract_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
         L.afx_f0_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
+        L.afx_f0_build_tables.argtypes = [i32, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
         L.afx_preprocess.argtypes = [vp, vp, C.c_int64, vp, i64p, i64p, i32p]
         L.afx_plan_set_timing.argtypes = [vp, i32]
         L.afx_plan_get_timings.argtypes = [vp, vp, vp, i32]
         _lib = L
     return _lib
+
+
+def f0_build_tables(sr: int, n_fft: int, hop: int, fmin: float, fmax: float) -> dict:
+    """Host-only: the pYIN tables of a configuration (no GPU needed)."""
+    info = np.zeros(8, np.int32)
+    _check(lib().afx_f0_build_tables(sr, n_fft, hop, fmin, fmax, info.ctypes.data, None, None, None), "afx_f0_build_tables")
+    band, nb = int(info[3]), int(info[2])
+    w = 2 * band + 1
+    beta, lt, freqs = np.zeros(100), np.zeros(2 * w * w), np.zeros(nb)
+    _check(lib().afx_f0_build_tables(sr, n_fft, hop, fmin, fmax, info.ctypes.data, beta.ctypes.data, lt.ctypes.data,
+                                     freqs.ctypes.data), "afx_f0_build_tables")
+    keys = ("min_period", "max_period", "n_bins", "band", "cap", "n_lag", "R", "slots")
+    return {**{k: int(v) for k, v in zip(keys, info)}, "beta": beta, "lt": lt.reshape(2, w, w), "freqs": freqs}
 
 
 def _check(rc: int, what: str):

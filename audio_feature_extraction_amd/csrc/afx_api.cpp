@@ -468,6 +468,21 @@ extern "C" int afx_extract_batch(afx_plan* pl, const void* samples, int sample_f
   return AFX_OK;
 }
 
+extern "C" int afx_f0_build_tables(int sr, int n_fft, int hop, double fmin, double fmax, int32_t* info,
+                                   double* beta, double* lt, double* freqs) {
+  HostF0Tables t;
+  std::string why;
+  if (!build_f0_tables(sr, n_fft, hop, fmin, fmax, t, why)) { set_error("afx_f0_build_tables: " + why); return AFX_ERR_UNSUPPORTED; }
+  if (info) {
+    const int32_t v[8] = {t.p.min_period, t.p.max_period, t.p.n_bins, t.p.band, t.p.cap, t.p.n_lag, t.p.R, t.p.slots};
+    std::memcpy(info, v, sizeof(v));
+  }
+  if (beta) std::memcpy(beta, t.beta.data(), t.beta.size() * sizeof(double));
+  if (lt) std::memcpy(lt, t.lt.data(), t.lt.size() * sizeof(double));
+  if (freqs) std::memcpy(freqs, t.freqs.data(), t.freqs.size() * sizeof(double));
+  return AFX_OK;
+}
+
 // ---- extract_f0 ---------------------------------------------------------------------------------
 static int f0_setup(afx_plan* pl, double fmin, double fmax) {
   if (pl->f0_ready && pl->f0_fmin == fmin && pl->f0_fmax == fmax) return AFX_OK;
@@ -499,6 +514,7 @@ static int f0_setup(afx_plan* pl, double fmin, double fmax) {
       (rc = up(ht.bexp, &pl->f0_dt.bexp)) != AFX_OK || (rc = up(ht.lt, &pl->f0_dt.lt)) != AFX_OK ||
       (rc = up(ht.freqs, &pl->f0_dt.freqs)) != AFX_OK)
     return rc;
+  if (const char* dbg = getenv("AFX_F0_DEBUG")) ht.p.debug = atoi(dbg);
   pl->f0_ht = ht;
   pl->f0_fmin = fmin; pl->f0_fmax = fmax;
   pl->f0_ready = true;

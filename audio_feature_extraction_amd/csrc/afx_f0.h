@@ -26,6 +26,7 @@ struct F0Params {
   int32_t cap;                         // candidate capacity per frame (>= number of possible troughs)
   int32_t band;                        // max_semitones_per_frame * bins_per_semitone (transition half-width)
   int32_t epb;                         // frames per block of k_f0_energy (64, 32 or 16)
+  int32_t debug;                       // AFX_F0_DEBUG: timing-only ablation switches (results are wrong when set)
   double sr, fmin;
   double tiny;                         // np.finfo(float64).tiny
   double c0;                           // log(tiny): log of a zero probability

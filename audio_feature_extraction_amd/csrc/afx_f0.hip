@@ -124,8 +124,6 @@ __global__ __launch_bounds__(64) void k_f0_energy(const float* __restrict__ ysig
 // ---------------------------------------------------------------------------------------------
 // k_f0_yin
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxR = 16;        // lags per lane (n_tau <= 1024)
-constexpr int kMaxSlots = 16;    // trough slots per lane (n_lag <= 1024)
 
 struct YinLds { size_t span, per_wave, tables, total; };
 __host__ __device__ inline YinLds yin_lds(const F0Params& fp) {
@@ -140,6 +138,8 @@ __host__ __device__ inline YinLds yin_lds(const F0Params& fp) {
 }
 size_t f0_yin_lds_bytes(const F0Params& fp) { return yin_lds(fp).total; }
 
+// RR >= lags per lane (fp.R), SS >= trough slots per lane (fp.slots): per-lane arrays are sized by them
+template <int RR, int SS>
 __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
                                                 const ClipDesc* __restrict__ clips,
                                                 const ClipInfo* __restrict__ info,
@@ -194,28 +194,21 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
     const double* F = Y + (size_t)f * hop;
 
     // ---- autocorrelation acf[tau] = sum_{i=1..W} y[i] y[i + tau]  (what irfft(rfft(y) rfft(y[W:0:-1])) [W:] is)
-    double acc[kMaxR];
+    double acc[RR];
 #pragma unroll
-    for (int r = 0; r < kMaxR; ++r) acc[r] = 0.0;
-    auto acf_loop = [&](auto RRt) {
-      constexpr int RR = decltype(RRt)::value;
-      for (int i = 1; i <= W; ++i) {
-        const double yi = F[i];
-        const double* q = F + i + lane;
+    for (int r = 0; r < RR; ++r) acc[r] = 0.0;
+#pragma unroll 4
+    for (int i = 1; i <= ((fp.debug & 4) ? 8 : W); ++i) {
+      const double yi = F[i];
+      const double* q = F + i + lane;
 #pragma unroll
-        for (int r = 0; r < RR; ++r) acc[r] = fma(yi, q[64 * r], acc[r]);
-      }
-    };
-    if (R <= 4) acf_loop(std::integral_constant<int, 4>());
-    else if (R <= 6) acf_loop(std::integral_constant<int, 6>());
-    else if (R <= 8) acf_loop(std::integral_constant<int, 8>());
-    else if (R <= 11) acf_loop(std::integral_constant<int, 11>());
-    else acf_loop(std::integral_constant<int, kMaxR>());
+      for (int r = 0; r < RR; ++r) acc[r] = fma(yi, q[64 * r], acc[r]);
+    }
     // ---- difference function d = (e[0] + e[tau]) [float32] - 2 acf [float64]
     const float* Erow = energy + slot * (int64_t)fp.n_tau_pad;
     const float e0 = Erow[0];
 #pragma unroll
-    for (int r = 0; r < kMaxR; ++r) {
+    for (int r = 0; r < RR; ++r) {
       const int tau = lane + 64 * r;
       if (r < R && tau < fp.n_tau) {
         double a = acc[r];
@@ -244,70 +237,84 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
       }
     }
     F0_WAVE_SYNC();
-    // ---- troughs (librosa.util.localmin, with the pyin rule for index 0)
-    double h[kMaxSlots], pr[kMaxSlots];
-    bool tr[kMaxSlots];
+    // ---- troughs (librosa.util.localmin, with the pyin rule for index 0), compacted in increasing lag:
+    // at most every second lag is a trough, so the threshold loop below runs over CS = ceil(n_troughs / 64)
+    // dense slots instead of one slot per 64 lags
+    constexpr int CSM = (SS + 1) / 2;                    // dense trough slots per lane
+    int n_tr = 0;
+    {
 #pragma unroll
-    for (int s = 0; s < kMaxSlots; ++s) {
-      h[s] = 0.0; pr[s] = 0.0; tr[s] = false;
-      if (s < slots) {
-        const int p = lane + 64 * s;
-        if (p < n_lag) {
-          const double x = X[p];
-          const double xm = p > 0 ? X[p - 1] : 0.0, xp = p + 1 < n_lag ? X[p + 1] : 0.0;
-          h[s] = x;
-          tr[s] = p == 0 ? (x < xp) : (p == n_lag - 1 ? (x < xm) : (x < xm && x <= xp));
+      for (int s = 0; s < SS; ++s) {
+        if (s < slots) {
+          const int p = lane + 64 * s;
+          bool t_here = false;
+          double x = 0.0;
+          if (p < n_lag) {
+            x = X[p];
+            const double xm = p > 0 ? X[p - 1] : 0.0, xp = p + 1 < n_lag ? X[p + 1] : 0.0;
+            t_here = p == 0 ? (x < xp) : (p == n_lag - 1 ? (x < xm) : (x < xm && x <= xp));
+          }
+          const unsigned long long m = __ballot(t_here);
+          if (t_here) { const int j = n_tr + lanes_below(m); CP[j] = x; CB[j] = p; }   // heights / lags, reused below
+          n_tr += __popcll(m);
         }
       }
     }
-    // ---- probabilities: for every threshold, a Boltzmann prior over the troughs below it
-    int n_tr = 0;
-#pragma unroll
-    for (int s = 0; s < kMaxSlots; ++s)
-      if (s < slots) n_tr += __popcll(__ballot(tr[s]));
+    F0_WAVE_SYNC();
     int cnt = 0;
     double vp = 0.0;
     if (n_tr > 0) {
-      for (int k = 1; k <= kF0Thresholds; ++k) {
-        const double thr = Tthr[k];
-        int n = 0;
+      const int CS = (n_tr + 63) >> 6;
+      double h[CSM], pr[CSM];
+      int lagp[CSM];
+      bool tr[CSM];
 #pragma unroll
-        for (int s = 0; s < kMaxSlots; ++s)
-          if (s < slots) n += __popcll(__ballot(tr[s] && h[s] < thr));
-        if (n == 0) continue;
+      for (int c = 0; c < CSM; ++c) {
+        const int j = lane + 64 * c;
+        tr[c] = c < CS && j < n_tr;
+        h[c] = tr[c] ? CP[j] : 0.0;
+        lagp[c] = tr[c] ? CB[j] : 0;
+        pr[c] = 0.0;
+      }
+      F0_WAVE_SYNC();
+      // ---- probabilities: for every threshold, a Boltzmann prior over the troughs below it
+      for (int k = 1; k <= ((fp.debug & 8) ? 4 : kF0Thresholds); ++k) {
+        const double thr = Tthr[k];
         // positions first (no memory), then one batch of table reads: a read under `if (below)` would put a
         // dependent LDS round trip into every slot of every threshold
-        int pos[kMaxSlots];
-        int running = 0;
+        int pos[CSM];
+        int n = 0;
 #pragma unroll
-        for (int s = 0; s < kMaxSlots; ++s) {
-          pos[s] = -1;
-          if (s < slots) {
-            const bool below = tr[s] && h[s] < thr;
+        for (int c = 0; c < CSM; ++c) {
+          pos[c] = -1;
+          if (c < CS) {
+            const bool below = tr[c] && h[c] < thr;
             const unsigned long long m = __ballot(below);
-            pos[s] = below ? running + lanes_below(m) : -1;
-            running += __popcll(m);
+            pos[c] = below ? n + lanes_below(m) : -1;
+            n += __popcll(m);
           }
         }
-        double ex[kMaxSlots];
+        if (n == 0) continue;
+        const double fact = Tfact[n], bk = Tbeta[k - 1];
+        double ex[CSM];
 #pragma unroll
-        for (int s = 0; s < kMaxSlots; ++s)
-          if (s < slots) ex[s] = Texp[pos[s] < 0 ? 0 : pos[s]];
+        for (int c = 0; c < CSM; ++c)
+          if (c < CS) ex[c] = Texp[pos[c] < 0 ? 0 : pos[c]];
 #pragma unroll
-        for (int s = 0; s < kMaxSlots; ++s)
-          if (s < slots && pos[s] >= 0) pr[s] += (Tfact[n] * ex[s]) * Tbeta[k - 1];
+        for (int c = 0; c < CSM; ++c)
+          if (c < CS && pos[c] >= 0) pr[c] += (fact * ex[c]) * bk;
       }
       // global minimum (first occurrence) collects the mass of the thresholds it does not undercut
       double hm = INFINITY;
 #pragma unroll
-      for (int s = 0; s < kMaxSlots; ++s)
-        if (s < slots && tr[s]) hm = fmin(hm, h[s]);
+      for (int c = 0; c < CSM; ++c)
+        if (tr[c]) hm = fmin(hm, h[c]);
       hm = wave_min_d(hm);
-      int pm = 1 << 30;
+      int jm = 1 << 30;
 #pragma unroll
-      for (int s = 0; s < kMaxSlots; ++s)
-        if (s < slots && tr[s] && h[s] == hm) pm = min(pm, lane + 64 * s);
-      pm = wave_min_i(pm);
+      for (int c = 0; c < CSM; ++c)
+        if (tr[c] && h[c] == hm) jm = min(jm, lane + 64 * c);
+      jm = wave_min_i(jm);
       int nbelow = 0;
       for (int k0 = 1; k0 <= kF0Thresholds; k0 += 64) {
         const int k = k0 + lane;
@@ -315,20 +322,20 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
       }
       const double extra = fp.no_trough_prob * Tcum[nbelow];
 #pragma unroll
-      for (int s = 0; s < kMaxSlots; ++s)
-        if (s < slots && tr[s] && lane + 64 * s == pm) pr[s] += extra;
+      for (int c = 0; c < CSM; ++c)
+        if (tr[c] && lane + 64 * c == jm) pr[c] += extra;
       // ---- candidates in increasing period: refine, map to a pitch bin
 #pragma unroll
-      for (int s = 0; s < kMaxSlots; ++s) {
-        if (s < slots) {
-          const bool nz = tr[s] && pr[s] != 0.0;
+      for (int c = 0; c < CSM; ++c) {
+        if (c < CS) {
+          const bool nz = tr[c] && pr[c] != 0.0;
           const unsigned long long m = __ballot(nz);
           if (nz) {
-            const int p = lane + 64 * s;
+            const int p = lagp[c];
             double shift = 0.0;
             if (p > 0 && p < n_lag - 1) {
               const double xm = X[p - 1], xp = X[p + 1];
-              const double a = xp + xm - 2.0 * h[s];
+              const double a = xp + xm - 2.0 * h[c];
               const double b = (xp - xm) / 2.0;
               shift = fabs(b) >= fabs(a) ? 0.0 : -b / a;
             }
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
             bf = bf < 0.0 ? 0.0 : (bf > (double)fp.n_bins ? (double)fp.n_bins : bf);
             const int j = cnt + lanes_below(m);
             CB[j] = (int)bf;
-            CP[j] = pr[s];
+            CP[j] = pr[c];
           }
           cnt += __popcll(m);
         }
@@ -468,8 +475,8 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
     if (t == 0) {
       for (int j = tid; j < S; j += kVitThreads) vcur[j] = j < nb ? olp[j] + c0 : lu + lpi_u;
     } else {
-      double gmax; int garg;
-      block_argmax(vprev, gmax, garg);
+      double gmax = 0.0; int garg = 0;
+      if (!(fp.debug & 2)) block_argmax(vprev, gmax, garg);
       const int gb = garg >= nb ? garg - nb : garg;
       const double* v0 = vprev;                          // voiced sources
       const double* v1 = vprev + nb;                     // unvoiced sources
@@ -495,7 +502,9 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
             upd(a1 + ww, b, m10, i10); upd(a1 + ws, b, m11, i11);
           }
         };
-        if (jb >= 2 * band && jb <= nb - 1 - 2 * band) {  // every source row is an interior row
+        if (fp.debug & 1) {
+          // ablation: no band walk
+        } else if (jb >= 2 * band && jb <= nb - 1 - 2 * band) {  // every source row is an interior row
           const double* p0 = v0 + (jb - band);
           const double* p1 = v1 + (jb - band);
 #pragma unroll 3
@@ -624,11 +633,21 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
                          int32_t* cand_cnt, double* cand_vp, int16_t* cand_bin, double* cand_prob,
                          int n_clips, int max_tmax) {
   const size_t lds = f0_yin_lds_bytes(fp);
-  hipError_t e = allow_lds(k_f0_yin, lds);
-  if (e != hipSuccess) return e;
   dim3 grid((max_tmax + kF0FramesPerBlock - 1) / kF0FramesPerBlock, n_clips);
-  hipLaunchKernelGGL(k_f0_yin, grid, dim3(256), lds, s, ysig, clips, info, energy, tb, fp, cand_cnt, cand_vp,
-                     cand_bin, cand_prob);
+  const int need = fp.R > fp.slots ? fp.R : fp.slots;
+#define AFX_YIN_LAUNCH(N)                                                                                       \
+  do {                                                                                                         \
+    hipError_t e2 = allow_lds(k_f0_yin<N, N>, lds);                                                            \
+    if (e2 != hipSuccess) return e2;                                                                           \
+    hipLaunchKernelGGL((k_f0_yin<N, N>), grid, dim3(256), lds, s, ysig, clips, info, energy, tb, fp, cand_cnt, \
+                       cand_vp, cand_bin, cand_prob);                                                          \
+  } while (0)
+  if (need <= 4) AFX_YIN_LAUNCH(4);
+  else if (need <= 6) AFX_YIN_LAUNCH(6);
+  else if (need <= 8) AFX_YIN_LAUNCH(8);
+  else if (need <= 11) AFX_YIN_LAUNCH(11);
+  else AFX_YIN_LAUNCH(16);
+#undef AFX_YIN_LAUNCH
   return hipGetLastError();
 }
 

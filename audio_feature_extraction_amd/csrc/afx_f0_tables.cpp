@@ -35,6 +35,7 @@ bool build_f0_tables(int sr, int n_fft, int hop, double fmin, double fmax, HostF
   p.tiny = 2.2250738585072014e-308;
   p.c0 = std::log(p.tiny);
   p.no_trough_prob = 0.01;
+  p.debug = 0;
   // frames per block of k_f0_energy: the span and the history must fit 150 KB of LDS
   p.epb = 0;
   for (int e : {64, 32, 16}) {

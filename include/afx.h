@@ -154,6 +154,15 @@ int afx_f0_batch(afx_plan* plan,
                  double* out_f0stats, int32_t* out_status,
                  double* out_f0, const int64_t* f0_offsets);
 
+/* Host-only (no device needed): the tables afx_f0_batch uploads, for inspection and tests.
+ * info[8] = min_period, max_period, n_pitch_bins, band (transition half-width), candidate
+ * capacity, lags kept, lags per lane, trough slots per lane.  beta[100] = Beta(2,18) mass of
+ * each threshold interval; lt[2][2*band+1][2*band+1] = log(switch * local + tiny) per source-row
+ * class (0 interior, 1..band low edge, band+1..2*band high edge) and offset; freqs[n_pitch_bins].
+ * Any pointer may be NULL. */
+int afx_f0_build_tables(int sr, int n_fft, int hop, double fmin, double fmax, int32_t* info,
+                        double* beta, double* lt, double* freqs);
+
 /* preprocess_audio(y) (F:58-74): pre-emphasis + trim of ONE host clip.
  * out_y receives the n pre-emphasised samples (host, n floats); the kept span
  * is out_y[*start .. *end). */

@@ -65,3 +65,29 @@ def test_no_device_means_loud_failure_not_fallback():
     ex = AudioFeatureExtractor()
     with pytest.raises(N.AfxError):
         ex.extract_mfcc(np.zeros(4096, np.float32))
+
+
+def test_f0_host_tables_match_the_pyin_oracle():
+    """The tables afx_f0_batch uploads (closed-form Beta masses, log-transition row classes, bin
+    frequencies) against oracle/pyin_ref.py, which builds them with scipy as librosa does."""
+    from oracle import pyin_ref as P
+    for sr, n_fft, hop in [(22050, 1024, 256), (16000, 512, 128), (44100, 2048, 512)]:
+        t = N.f0_build_tables(sr, n_fft, hop, P.C2_HZ, P.C7_HZ)
+        mn, mx = P.periods(sr, P.C2_HZ, P.C7_HZ, n_fft, n_fft // 2)
+        tb = P.pyin_tables(sr, P.C2_HZ, P.C7_HZ, hop)
+        assert (t["min_period"], t["max_period"], t["n_bins"]) == (mn, mx, tb["n_pitch_bins"])
+        assert 2 * t["band"] + 1 == tb["transition_width"]
+        assert t["cap"] >= (t["n_lag"] + 1) // 2
+        np.testing.assert_allclose(t["beta"], tb["beta_probs"], rtol=0, atol=5e-15)   # closed form vs scipy.special.betainc
+        nb, band = t["n_bins"], t["band"]
+        np.testing.assert_allclose(t["freqs"], P.C2_HZ * 2 ** (np.arange(nb) / 120), rtol=4e-16)     # pow: one ulp
+        logA = np.log(tb["transition"] + np.finfo(np.float64).tiny)
+        w = 2 * band + 1
+        for b in list(range(0, band + 2)) + [nb // 2] + list(range(nb - band - 2, nb)):
+            rc = 1 + b if b < band else (1 + band + (nb - 1 - b) if b > nb - 1 - band else 0)
+            for d in range(w):
+                j = b + d - band
+                if 0 <= j < nb:
+                    assert abs(t["lt"][0, rc, d] - logA[b, j]) < 1e-13            # voiced -> voiced (stay)
+                    assert abs(t["lt"][1, rc, d] - logA[b, nb + j]) < 1e-13       # voiced -> unvoiced (switch)
+                    assert abs(t["lt"][0, rc, d] - logA[nb + b, nb + j]) < 1e-13
