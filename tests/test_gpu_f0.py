@@ -88,3 +88,37 @@ def test_f0_flags_nonfinite_and_short_clips(plan):
     assert out["status"].tolist() == [N.CLIP_NONFINITE, 0, 0]
     check_clip(f0[1], out["stats"][1], clips[1], "short")
     check_clip(f0[2], out["stats"][2], clips[2], "one-sample")
+
+
+@pytest.mark.parametrize("sr,n_fft,hop", [(16000, 512, 128), (44100, 2048, 512)])
+def test_f0_other_frame_sizes(sr, n_fft, hop):
+    """BASELINE configs 3 and 5 shapes: different lag counts, pitch-range clipping (max_period = n_fft/2 - 1)."""
+    ctx = N.Context(0)
+    pl = N.Plan(ctx, N.make_params(sr, n_fft, hop, 13))
+    try:
+        t = np.arange(int(sr * 0.6)) / sr
+        rng = np.random.default_rng(5)
+        clips = []
+        for f in (130.0, 310.0):
+            ph = 2 * np.pi * f * t * (1 + 0.01 * np.sin(2 * np.pi * 4 * t))
+            clips.append((0.3 * np.sin(ph) + 0.08 * np.sin(2 * ph) + 0.004 * rng.standard_normal(t.size)).astype(np.float32))
+        lengths = np.array([c.size for c in clips], np.int64)
+        pad = (lengths + 3) // 4 * 4
+        offsets = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.int64)
+        buf = np.zeros(int(pad.sum()), np.float32)
+        for c, o in zip(clips, offsets):
+            buf[o:o + c.size] = c
+        out = pl.f0_batch(buf, offsets, lengths, P.C2_HZ, P.C7_HZ, flags=0, want_frames=True)
+        for i, c in enumerate(clips):
+            T = 1 + c.size // hop
+            f0 = out["f0_flat"][out["f0_offsets"][i]: out["f0_offsets"][i] + T]
+            ref, _, _ = P.pyin(c, sr=sr, frame_length=n_fft, hop_length=hop)
+            same = np.isnan(f0) == np.isnan(ref)
+            v = ~np.isnan(f0) & ~np.isnan(ref)
+            same[v] &= np.abs(f0[v] - ref[v]) <= 1e-9 * ref[v]
+            assert same.mean() >= 0.99, (sr, i, same.mean())
+            r = P.extract_f0(c, sr=sr, frame_length=n_fft, hop_length=hop)
+            assert abs(out["stats"][i][0] - r["f0_mean"]) <= 5e-3 * max(r["f0_mean"], 1.0)
+    finally:
+        pl.close()
+        ctx.close()
