@@ -207,6 +207,36 @@ class AudioFeatureExtractor:
             self.logger.error(f"特徵提取失敗: {str(e)}")
             raise
 
+    # ------------------------------------------------------------------ per-frame export
+    def extract_frame_features(self, audio_path: str) -> Dict[str, np.ndarray]:
+        """The per-frame matrices the reference computes and then reduces (feature_extractor.py:127-138,
+        :164, :87), in the layout its experiment scripts save and its DTW aligner reads
+        (04_feature_extraction_experiment/feature_extraction.py:191-215, 340-352): ``mfcc`` is
+        ``vstack([mfcc, delta, delta2])`` of shape (3*n_mfcc, T) float32, ``energy`` the RMS row (T,)
+        float32, ``f0`` the pYIN track (T,) float64 with NaN on unvoiced frames -- all of the
+        preprocessed signal, all computed on the GPU."""
+        y, _ = self.load_audio(audio_path)
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        flags = _native.FLAG_PREEMPH | _native.FLAG_TRIM
+        off, ln = np.zeros(1, np.int64), np.array([y.size], np.int64)
+        plan = self._plan()
+        out = plan.extract_batch(y, off, ln, flags=flags, want_frames=True)
+        if out["status"][0] != _native.CLIP_OK:
+            raise _status_error(int(out["status"][0]), "extract_frame_features", int(out["nframes"][0]))
+        fr = out["frames"][0]
+        T = int(out["nframes"][0])
+        f0 = plan.f0_batch(y, off, ln, float(self.f0_min), float(self.f0_max), flags=flags, want_frames=True)
+        return {
+            "mfcc": np.vstack([fr["mfcc"], fr["mfcc_delta"], fr["mfcc_delta2"]]),
+            "energy": fr["rms"][0].copy(),
+            "f0": f0["f0_flat"][:T].copy(),
+        }
+
+    @staticmethod
+    def save_frame_features(features: Dict[str, np.ndarray], npz_path: str) -> None:
+        """``np.savez(npz_path, **features)`` -- the reference's on-disk schema for frame-level features."""
+        np.savez(npz_path, **features)
+
     def batch_process(self, audio_dir: str) -> List[Dict[str, Any]]:
         """批量處理音頻文件 (feature_extractor.py:215-237): every ``*.wav`` directly inside
         ``audio_dir`` in glob order; a failing file is logged and left out.  Files are

@@ -138,3 +138,30 @@ def test_speech_and_music_configs_batch(sr, n_fft, hop, K):
         check_stats(out["stats"][i], oracle_stats(y, sr, n_fft, hop, K), K, f"{sr}/{i}")
     plan.close()
     ctx.close()
+
+
+def test_frame_feature_export_matches_oracle_and_round_trips(tmp_path):
+    from oracle import cpu_ref as R
+    from oracle import pyin_ref as P
+    y = make_clip(81, 22050, 1.5, speechy=True)
+    p = str(tmp_path / "c.wav")
+    wavio.write_wav_pcm16(p, y, 22050)
+    ex = AudioFeatureExtractor()
+    fr = ex.extract_frame_features(p)
+    yd, _ = ex.load_audio(p)
+    yp, _ = R.preprocess_audio(yd)
+    ref = R.extract_mfcc(yp, 22050, 13, 1024, 256, return_frames=True)
+    T = 1 + yp.size // 256
+    assert fr["mfcc"].shape == (39, T) and fr["mfcc"].dtype == np.float32
+    assert fr["energy"].shape == (T,) and fr["f0"].shape == (T,) and fr["f0"].dtype == np.float64
+    scale = np.abs(ref["mfcc"]).max(axis=1, keepdims=True)
+    assert (np.abs(fr["mfcc"][:13] - ref["mfcc"]) <= 1e-4 * scale).all()
+    assert (np.abs(fr["mfcc"][13:26] - ref["mfcc_delta"]) <= 1e-4 * scale).all()
+    np.testing.assert_allclose(fr["energy"], R.extract_energy(yp, 1024, 256, return_frames=True)["rms"][0], rtol=1e-5, atol=1e-7)
+    f0_ref, _, _ = P.pyin(yp)
+    same = np.isnan(fr["f0"]) == np.isnan(f0_ref)
+    assert same.mean() >= 0.99
+    out = str(tmp_path / "frames.npz")
+    ex.save_frame_features(fr, out)
+    with np.load(out) as z:
+        assert sorted(z.files) == ["energy", "f0", "mfcc"] and z["mfcc"].shape == (39, T)
