@@ -1648,10 +1648,12 @@ __global__ __launch_bounds__(256) void k_stats(const ClipDesc* __restrict__ clip
   if (row < K) {
     const float* x = mfcc + cd.frame_base * (int64_t)K + (int64_t)row * cd.tpad;
     double s = 0.0;
+#pragma unroll 8
     for (int t = lane; t < T; t += 64) s += (double)x[t];
     const double mean = wave_sum_d(s) * invT;
     const float meanf = (float)mean;
     double s2 = 0.0, sd1 = 0.0, sd2 = 0.0;
+#pragma unroll 2
     for (int t = lane; t < T; t += 64) {
       const float d = x[t] - meanf;
       s2 += (double)d * (double)d;
@@ -1661,10 +1663,10 @@ __global__ __launch_bounds__(256) void k_stats(const ClipDesc* __restrict__ clip
       const int tc = t < 4 ? 4 : (t > T - 5 ? T - 5 : t);
       const float* c = x + tc;
       const double d1 = (4.0 * ((double)c[4] - (double)c[-4]) + 3.0 * ((double)c[3] - (double)c[-3]) +
-                         2.0 * ((double)c[2] - (double)c[-2]) + ((double)c[1] - (double)c[-1])) / 60.0;
+                         2.0 * ((double)c[2] - (double)c[-2]) + ((double)c[1] - (double)c[-1])) * (1.0 / 60.0);
       const double d2 = (28.0 * ((double)c[4] + (double)c[-4]) + 7.0 * ((double)c[3] + (double)c[-3]) -
                          8.0 * ((double)c[2] + (double)c[-2]) - 17.0 * ((double)c[1] + (double)c[-1]) -
-                         20.0 * (double)c[0]) / 462.0;
+                         20.0 * (double)c[0]) * (1.0 / 462.0);
       const float d1f = (float)d1, d2f = (float)d2;
       sd1 += (double)d1f; sd2 += (double)d2f;
       if (fo) {
