@@ -71,7 +71,7 @@ class AudioFeatureExtractor:
 
         logging.basicConfig(level=logging.INFO)
         self.logger = logging.getLogger(__name__)
-        self._plans: Dict[int, _native.Plan] = {}
+        self._plans: Dict[Tuple[int, int], _native.Plan] = {}
         self._plan_lock = threading.Lock()
 
     # ------------------------------------------------------------------ plumbing
@@ -85,16 +85,18 @@ class AudioFeatureExtractor:
             return [self.device]
         return [int(d) for d in self.device]
 
-    def _plan(self, device: Optional[int] = None) -> _native.Plan:
+    def _plan(self, device: Optional[int] = None, lane: int = 0) -> _native.Plan:
+        """One plan (own context + stream) per (device, lane); lanes > 0 are the extra in-flight
+        workers ``batch_process`` runs per GPU."""
         if device is None:
             device = self._devices()[0]
         with self._plan_lock:
-            pl = self._plans.get(device)
+            pl = self._plans.get((device, lane))
             if pl is None:
                 params = _native.make_params(self.sr, self.frame_length, self.hop_length, self.n_mfcc,
                                              self.n_mels, self.window, self.pre_emphasis)
                 pl = _native.Plan(_native.Context(device), params)
-                self._plans[device] = pl
+                self._plans[(device, lane)] = pl
             return pl
 
     def _uses_reference_stages(self) -> bool:

@@ -87,8 +87,13 @@ def _pack(clips: List[np.ndarray], dtype) -> Tuple[np.ndarray, np.ndarray, np.nd
     return buf, offsets, lengths
 
 
-def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 1024 * 1024) -> List[Dict[str, Any]]:
-    """Decode -> shard over GPUs -> fused extract -> dicts in input (glob) order."""
+WORKERS_PER_GPU = 3     # sub-batches in flight per GPU (own context / stream / thread): copies, the bandwidth-bound
+                        # kernels and the host round trip of one hide under the frame kernel of another
+
+
+def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 1024 * 1024,
+                  workers_per_gpu: int = WORKERS_PER_GPU) -> List[Dict[str, Any]]:
+    """Decode -> shard over GPUs (and over a few workers per GPU) -> fused extract -> dicts in input (glob) order."""
     log = extractor.logger
     n = len(files)
     if n == 0:
@@ -114,12 +119,15 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
     nframes = np.zeros(n, np.int32)
     f0s = np.zeros((n, 4), np.float64)
     want_f0 = getattr(extractor, "_f0_on_gpu", lambda: False)()
-    parts = lpt_partition([decoded[i][1].size for i in ok], len(devices))
+    lanes = [(d, w) for d in devices for w in range(max(1, int(workers_per_gpu)))]
+    if len(ok) < 4 * len(lanes):                       # small jobs: one worker per GPU
+        lanes = [(d, 0) for d in devices]
+    parts = lpt_partition([decoded[i][1].size for i in ok], len(lanes))
     flags = _native.FLAG_PREEMPH | _native.FLAG_TRIM
 
-    def worker(dev, idxs):
+    def worker(lane, idxs):
         try:
-            plan = extractor._plan(dev)
+            plan = extractor._plan(lane[0], lane[1])
             for kind, fmt, dt in (("s16", _native.FMT_S16, np.int16), ("f32", _native.FMT_F32, np.float32)):
                 sel = [ok[j] for j in idxs if decoded[ok[j]][0] == kind]
                 pos = 0
@@ -148,7 +156,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
                 if errors[ok[j]] is None and status[ok[j]] < 0:
                     errors[ok[j]] = e
 
-    threads = [threading.Thread(target=worker, args=(d, p)) for d, p in zip(devices, parts) if p]
+    threads = [threading.Thread(target=worker, args=(ln, p)) for ln, p in zip(lanes, parts) if p]
     for t in threads:
         t.start()
     for t in threads:

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for m in "$@"; do
-  AFX_DEBUG_SKIP=$m python bench.py --steps 10 --warmup 2 --cpu-clips 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('skip=$m', 'frames_ms=%.3f'%d['roofline']['kernels_ms_per_step']['frames'])"
+  AFX_DEBUG_SKIP=$m python bench.py --steps 10 --warmup 2 --cpu-clips 0 --streams 1 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('skip=$m', 'frames_ms=%.3f'%d["roofline"]["avg_launch_ms"])"
 done
