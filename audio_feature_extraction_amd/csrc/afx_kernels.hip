@@ -139,17 +139,29 @@ __global__ __launch_bounds__(256) void k_trim_blocks(const void* __restrict__ sa
   const float* base = (const float*)samples + cd.off;
   int nf = 0;
 
-  // fast route: the wave's whole span is inside the clip, float32, aligned, and made of 256-sample runs
+  // fast route: the wave's whole span is inside the clip, aligned, and made of 256-sample runs
   const int64_t s0 = bfirst * th, s1 = s0 + (int64_t)kTrimPerWave * th;
-  const bool fast = kp.fmt == AFX_FMT_F32 && (th == 256 || th == 512) && s0 > 0 && s1 <= N && (((cd.off + s0) & 3) == 0);
+  const bool fast = (th == 256 || th == 512) && s0 > 0 && s1 <= N && (((cd.off + s0) & 3) == 0);
   if (fast) {
     constexpr int MAXR = kTrimPerWave * 2;
     const int nr = kTrimPerWave * (th >> 8);
     float4 q[MAXR];
+    if (kp.fmt == AFX_FMT_F32) {
 #pragma unroll
-    for (int r = 0; r < MAXR; ++r)
-      if (r < nr) q[r] = *reinterpret_cast<const float4*>(base + s0 + 256 * r + 4 * lane);
-    float carry = base[s0 - 1];                                 // sample before the span (lane 0 of run 0)
+      for (int r = 0; r < MAXR; ++r)
+        if (r < nr) q[r] = *reinterpret_cast<const float4*>(base + s0 + 256 * r + 4 * lane);
+    } else {                                                    // int16: 8-byte loads, /32768 as libsndfile
+      const int16_t* b16 = (const int16_t*)samples + cd.off;
+      const float sc = 1.0f / 32768.0f;
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r)
+        if (r < nr) {
+          const int2 w = *reinterpret_cast<const int2*>(b16 + s0 + 256 * r + 4 * lane);
+          q[r] = make_float4((float)(short)(w.x & 0xffff) * sc, (float)(short)(w.x >> 16) * sc,
+                             (float)(short)(w.y & 0xffff) * sc, (float)(short)(w.y >> 16) * sc);
+        }
+    }
+    float carry = ld_sample(samples, kp.fmt, cd.off + s0 - 1);   // sample before the span (lane 0 of run 0)
     float acc = 0.f;
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
