@@ -165,3 +165,21 @@ def test_frame_feature_export_matches_oracle_and_round_trips(tmp_path):
     ex.save_frame_features(fr, out)
     with np.load(out) as z:
         assert sorted(z.files) == ["energy", "f0", "mfcc"] and z["mfcc"].shape == (39, T)
+
+
+def test_batch_process_with_several_workers_per_gpu(tmp_path):
+    """Enough files that batch_process runs its three in-flight workers per GPU (parallel.WORKERS_PER_GPU):
+    same dicts, same (glob) order as file-by-file extract_features."""
+    from pathlib import Path
+    for i in range(14):
+        wavio.write_wav_pcm16(str(tmp_path / f"w{i:02d}.wav"), make_clip(200 + i, 22050, 0.5 + 0.05 * i), 22050)
+    ex = AudioFeatureExtractor()
+    res = ex.batch_process(str(tmp_path))
+    paths = [str(p) for p in Path(tmp_path).glob("*.wav")]
+    assert [d["file_path"] for d in res] == paths
+    assert len(ex._plans) >= 3                                          # lanes (device 0, 0..2) were used
+    for d in res[::5]:
+        one = ex.extract_features(d["file_path"])
+        assert list(one) == KEYS
+        for k in KEYS[1:]:
+            np.testing.assert_allclose(np.asarray(d[k], np.float64), np.asarray(one[k], np.float64), rtol=1e-6, atol=1e-9)
