@@ -122,3 +122,33 @@ def test_f0_other_frame_sizes(sr, n_fft, hop):
     finally:
         pl.close()
         ctx.close()
+
+
+def test_f0_random_mixtures(plan):
+    """Voiced / noisy / silent stretches in random order: onsets, offsets and octave ambiguities."""
+    rng = np.random.default_rng(11)
+    clips = []
+    for i in range(8):
+        parts = []
+        for _ in range(int(rng.integers(2, 5))):
+            n = int(rng.integers(1500, 7000))
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                parts.append(np.zeros(n, np.float32))
+            elif kind == 1:
+                parts.append((0.05 * rng.standard_normal(n)).astype(np.float32))
+            else:
+                f = float(rng.uniform(80, 900))
+                seg = voiced_tone(f, n / SR, vib=float(rng.uniform(0, 0.03)), seed=int(rng.integers(1 << 30)))[:n]
+                parts.append(float(rng.uniform(0.1, 1.0)) * seg)
+        clips.append(np.concatenate(parts).astype(np.float32))
+    out, f0 = run(plan, clips, flags=0)
+    worst = 1.0
+    for i, c in enumerate(clips):
+        ref, _, _ = P.pyin(c, sr=SR, frame_length=1024, hop_length=256)
+        same = np.isnan(f0[i]) == np.isnan(ref)
+        v = ~np.isnan(f0[i]) & ~np.isnan(ref)
+        same[v] &= np.abs(f0[i][v] - ref[v]) <= 1e-9 * ref[v]
+        worst = min(worst, same.mean())
+        assert same.mean() >= 0.97, (i, same.mean(), np.flatnonzero(~same)[:12])
+    assert worst >= 0.97
