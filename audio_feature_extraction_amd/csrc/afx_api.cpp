@@ -573,6 +573,21 @@ static int f0_chunk(afx_plan* pl, const void* d_samples, int fmt, const int64_t*
   HIP_TRY(hipMemcpyAsync(h_info.data(), d_info, n * sizeof(ClipInfo), hipMemcpyDeviceToHost, s));
   if (out_f0 && f0_count) HIP_TRY(hipMemcpyAsync(out_f0, d_f0, f0_count * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (const char* dump = getenv("AFX_F0_DUMP")) {                       // diagnostics: the sparse observation columns
+    std::vector<int32_t> cnt(frames); std::vector<double> vp(frames), pr((size_t)frames * fp.cap);
+    std::vector<int16_t> bn((size_t)frames * fp.cap);
+    HIP_TRY(hipMemcpy(cnt.data(), pl->f0_cnt.p, frames * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(vp.data(), pl->f0_vp.p, frames * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pr.data(), pl->f0_prob.p, pr.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(bn.data(), pl->f0_bin.p, bn.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(dump, "wb")) {
+      const int64_t hdr[2] = {frames, fp.cap};
+      fwrite(hdr, sizeof(hdr), 1, f);
+      fwrite(cnt.data(), sizeof(int32_t), cnt.size(), f); fwrite(vp.data(), sizeof(double), vp.size(), f);
+      fwrite(bn.data(), sizeof(int16_t), bn.size(), f); fwrite(pr.data(), sizeof(double), pr.size(), f);
+      fclose(f);
+    }
+  }
   for (int i = 0; i < n; ++i) out_status[i] = h_info[i].nonfinite ? AFX_CLIP_NONFINITE : AFX_CLIP_OK;
   return AFX_OK;
 }

@@ -355,11 +355,18 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
       for (int j = lane; j < cnt; j += 64) {
         const int b = CB[j];
         const bool keep = (j == cnt - 1) || CB[j + 1] != b;
-        if (keep && b < fp.n_bins) vp += CP[j];
         cand_bin[slot * fp.cap + j] = (int16_t)(keep ? b : -1);
         cand_prob[slot * fp.cap + j] = CP[j];
+        if (!keep) CB[j] = -1;
       }
-      vp = wave_sum_d(vp);
+      F0_WAVE_SYNC();
+      // voiced_prob = np.sum(observation[:n_bins], axis=0): numpy adds the rows one after another, i.e. the kept
+      // candidates in ascending bin order (descending j), sequentially.  The order is reproduced because the sum is
+      // mathematically 1 for a strongly voiced frame and the unvoiced observation is (1 - sum) / n_bins: 0 or 1e-19.
+      for (int j = cnt - 1; j >= 0; --j) {
+        const int b = CB[j];
+        if (b >= 0 && b < fp.n_bins) vp += CP[j];
+      }
       F0_WAVE_SYNC();
     }
     if (lane == 0) {
