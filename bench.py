@@ -122,8 +122,8 @@ def cpu_baseline(samples, offsets, lengths, n_single: int, n_pool: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU (default: the BASELINE config)")
     ap.add_argument("--cpu-clips", type=int, default=1000, help="clips timed on one CPU core (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-pool-clips", type=int, default=8000)
@@ -185,7 +185,11 @@ def main() -> None:
         lanes.append({"ctx": ctx, "plan": plan, "dbuf": dbuf, "offsets": offsets[lo:hi] - base,
                       "lengths": lengths[lo:hi], "out": None})
 
-    def lane_steps(lane, k):
+    stagger = [0.0]          # seconds between the first submissions of consecutive lanes
+
+    def lane_steps(lane, k, delay=0.0):
+        if delay > 0.0:
+            time.sleep(delay)
         for _ in range(k):
             lane["out"] = lane["plan"].extract_batch(lane["dbuf"], lane["offsets"], lane["lengths"], out=lane["out"])
 
@@ -193,7 +197,9 @@ def main() -> None:
         if S == 1:
             lane_steps(lanes[0], k)
             return
-        th = [threading.Thread(target=lane_steps, args=(ln, k)) for ln in lanes]
+        # lanes that start together stay in lockstep (their frame kernels co-run and finish together); a start
+        # offset of 1/S of a lane's step keeps one lane's frame kernel over the others' small kernels
+        th = [threading.Thread(target=lane_steps, args=(ln, k, i * stagger[0])) for i, ln in enumerate(lanes)]
         for t in th:
             t.start()
         for t in th:
@@ -205,6 +211,10 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    run_steps(1)
+    t_w = time.perf_counter()
+    lane_steps(lanes[0], 3)
+    stagger[0] = (time.perf_counter() - t_w) / 3 / S
     run_steps(max(args.warmup, 1))
     for ln in lanes:
         assert int((ln["out"]["status"] != 0).sum()) == 0, "synthetic clips must all succeed"
