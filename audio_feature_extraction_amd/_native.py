@@ -3,6 +3,7 @@ fallback: if the HIP library is missing or no GPU is visible, calls fail loudly.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 import threading
 
@@ -169,9 +170,12 @@ class Context:
         h = C.c_void_p()
         _check(lib().afx_init(int(device), C.byref(h)), f"afx_init(device={device})")
         self.handle, self.device = h, int(device)
+        self._plans = weakref.WeakSet()        # closed before the context itself (their workspace lives on its stream)
 
     def close(self):
         if self.handle:
+            for pl in list(self._plans):
+                pl.close()
             lib().afx_destroy(self.handle)
             self.handle = None
 
@@ -188,6 +192,7 @@ class Plan:
         h = C.c_void_p()
         _check(lib().afx_plan_create(ctx.handle, C.byref(params), C.byref(h)), "afx_plan_create")
         self.handle = h
+        ctx._plans.add(self)
         self.n_stats = 4 * params.n_mfcc + 3
 
     def close(self):

@@ -37,6 +37,7 @@ struct afx_ctx {
 
 struct afx_plan {
   afx_ctx* ctx = nullptr;
+  int device = 0;             // copy: the plan may be destroyed after its context by a garbage-collected binding
   afx_params p{};
   KParams kp{};
   HostTables ht;
@@ -187,7 +188,7 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
   if (p->n_fft > 2048) { set_error("frame_length > 2048 is not supported by the LDS-resident FFT"); return AFX_ERR_UNSUPPORTED; }
   HIP_TRY(hipSetDevice(ctx->device));
   afx_plan* pl = new afx_plan();
-  pl->ctx = ctx; pl->p = *p;
+  pl->ctx = ctx; pl->device = ctx->device; pl->p = *p;
   build_host_tables(*p, pl->ht);
   const size_t lds = frames_lds_bytes(p->n_fft, p->hop);
   if (lds == 0 || lds > 160 * 1024) {
@@ -241,7 +242,7 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
 
 extern "C" void afx_plan_destroy(afx_plan* pl) {
   if (!pl) return;
-  (void)hipSetDevice(pl->ctx->device);
+  (void)hipSetDevice(pl->device);
   for (void* d : pl->table_allocs) (void)hipFree(d);
   for (void* q : pl->f0_allocs) (void)hipFree(q);
   release(pl->f0_in); release(pl->f0_ysig); release(pl->f0_energy); release(pl->f0_cnt); release(pl->f0_vp);
@@ -258,7 +259,7 @@ extern "C" void afx_plan_destroy(afx_plan* pl) {
 
 extern "C" int afx_plan_set_timing(afx_plan* pl, int enable) {
   if (!pl) { set_error("afx_plan_set_timing: null plan"); return AFX_ERR_INVALID; }
-  HIP_TRY(hipSetDevice(pl->ctx->device));
+  HIP_TRY(hipSetDevice(pl->device));
   if (enable && !pl->ev_ready) {
     for (int k = 0; k < AFX_K_COUNT; ++k) { HIP_TRY(hipEventCreate(&pl->ev[k][0])); HIP_TRY(hipEventCreate(&pl->ev[k][1])); }
     pl->ev_ready = true;
@@ -453,7 +454,8 @@ extern "C" int afx_extract_batch(afx_plan* pl, const void* samples, int sample_f
   if (sample_fmt != AFX_FMT_F32 && sample_fmt != AFX_FMT_S16) { set_error("unknown sample format"); return AFX_ERR_INVALID; }
   if (mem_kind != AFX_MEM_HOST && mem_kind != AFX_MEM_DEVICE) { set_error("unknown mem_kind"); return AFX_ERR_INVALID; }
   if (n_clips == 0) return AFX_OK;
-  HIP_TRY(hipSetDevice(pl->ctx->device));
+  (void)hipGetLastError();      // a stale error of an unrelated earlier call must not be blamed on this one
+  HIP_TRY(hipSetDevice(pl->device));
   const int nstat = 4 * pl->p.n_mfcc + 3;
   const int kChunk = 32768;   // gridDim.y limit is 65535
   for (int c0 = 0; c0 < n_clips; c0 += kChunk) {
@@ -603,7 +605,8 @@ extern "C" int afx_f0_batch(afx_plan* pl, const void* samples, int sample_fmt, i
   if (sample_fmt != AFX_FMT_F32 && sample_fmt != AFX_FMT_S16) { set_error("unknown sample format"); return AFX_ERR_INVALID; }
   if (mem_kind != AFX_MEM_HOST && mem_kind != AFX_MEM_DEVICE) { set_error("unknown mem_kind"); return AFX_ERR_INVALID; }
   if (n_clips == 0) return AFX_OK;
-  HIP_TRY(hipSetDevice(pl->ctx->device));
+  (void)hipGetLastError();
+  HIP_TRY(hipSetDevice(pl->device));
   int rc;
   if ((rc = f0_setup(pl, fmin, fmax)) != AFX_OK) return rc;
   const void* d_samples = samples;
@@ -641,7 +644,8 @@ extern "C" int afx_preprocess(afx_plan* pl, const float* y, int64_t n, float* ou
     set_error("afx_preprocess: null/invalid argument");
     return AFX_ERR_INVALID;
   }
-  HIP_TRY(hipSetDevice(pl->ctx->device));
+  (void)hipGetLastError();
+  HIP_TRY(hipSetDevice(pl->device));
   hipStream_t s = pl->ctx->stream;
   const int64_t off = 0;
   int rc;

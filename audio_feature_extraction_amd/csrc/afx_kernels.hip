@@ -1568,10 +1568,11 @@ __global__ __launch_bounds__(256) void k_dct(const ClipDesc* __restrict__ clips,
   }
 }
 
-// k_dct16: the same for n_mels % 16 == 0 and n_mfcc <= 16 (the reference's 128 / 13).  A wave takes kDctTiles
+// k_dct16<NCG>: the same for n_mels % 16 == 0 and n_mfcc <= 16 NCG <= 48 (the reference's 128 / 13).  A wave takes kDctTiles
 // tiles; lane (f, q) fetches filters 16 s + 4 q + {0..3} of frame f with one 16-byte load (a wave-load is 1 KB
 // contiguous), all loads of its tiles issued before the first use; the DCT matrix sits in registers.
 constexpr int kDctTiles = 2;
+template <int NCG>
 __global__ __launch_bounds__(256) void k_dct16(const ClipDesc* __restrict__ clips,
                                                const ClipInfo* __restrict__ info,
                                                const float* __restrict__ dctP, KParams kp,
@@ -1597,32 +1598,44 @@ __global__ __launch_bounds__(256) void k_dct16(const ClipDesc* __restrict__ clip
     for (int s = 0; s < 8; ++s)
       x[j][s] = (s < S && t0 < ci.T) ? *reinterpret_cast<const float4*>(tile + s * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  float a[8][4];
+  float a[NCG][8][4];
 #pragma unroll
-  for (int s = 0; s < 8; ++s)
+  for (int g = 0; g < NCG; ++g)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a[s][c] = s < S ? dctP[(s * 4 + c) * 64 + lane] : 0.f;
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[g][s][c] = s < S ? dctP[((g * S + s) * 4 + c) * 64 + lane] : 0.f;
 #pragma unroll
   for (int j = 0; j < kDctTiles; ++j) {
     const int t0 = (tile0 + j) * 16;
     if (t0 >= ci.T) break;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NCG][2];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       if (s < S) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], fmaxf(x[j][s].x, theta), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][1], fmaxf(x[j][s].y, theta), acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][2], fmaxf(x[j][s].z, theta), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], fmaxf(x[j][s].w, theta), acc1, 0, 0, 0);
+        const float b0 = fmaxf(x[j][s].x, theta), b1 = fmaxf(x[j][s].y, theta);
+        const float b2 = fmaxf(x[j][s].z, theta), b3 = fmaxf(x[j][s].w, theta);
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+          acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][s][0], b0, acc[g][0], 0, 0, 0);
+          acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][s][1], b1, acc[g][1], 0, 0, 0);
+          acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][s][2], b2, acc[g][0], 0, 0, 0);
+          acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][s][3], b3, acc[g][1], 0, 0, 0);
+        }
       }
     }
-    const f32x4 acc = acc0 + acc1;
     if (t0 + f < ci.T) {
       float* out = mfcc + cd.frame_base * (int64_t)K + t0 + f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = q * 4 + r;
-        if (k < K) out[(int64_t)k * cd.tpad] = acc[r];
+      for (int g = 0; g < NCG; ++g) {
+        const f32x4 r4 = acc[g][0] + acc[g][1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = g * 16 + q * 4 + r;
+          if (k < K) out[(int64_t)k * cd.tpad] = r4[r];
+        }
       }
     }
   }
@@ -1837,9 +1850,12 @@ hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
 
 hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
                       const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax) {
-  if (tb.dctP && kp.n_mels % 16 == 0 && kp.n_mels <= 128 && kp.n_mfcc <= 16) {
+  if (tb.dctP && kp.n_mels % 16 == 0 && kp.n_mels <= 128 && kp.n_mfcc <= 48) {
     dim3 g16(((max_tmax + 15) / 16 + 4 * kDctTiles - 1) / (4 * kDctTiles), n_clips);
-    hipLaunchKernelGGL(k_dct16, g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
+    const int ncg = (kp.n_mfcc + 15) / 16;
+    if (ncg == 1) hipLaunchKernelGGL(k_dct16<1>, g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
+    else if (ncg == 2) hipLaunchKernelGGL(k_dct16<2>, g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
+    else hipLaunchKernelGGL(k_dct16<3>, g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
     return hipGetLastError();
   }
   dim3 grid(((max_tmax + 15) / 16 + 3) / 4, n_clips);

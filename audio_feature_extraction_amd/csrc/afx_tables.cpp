@@ -215,17 +215,18 @@ static void build_dct_blocks(const afx_params& p, const std::vector<float>& D, D
         if (k < K) d.A[((size_t)c * NI + i) * 64 + l] = D[(size_t)k * M + m];
       }
   // k_dct16: lane (f, q) fetches filters 16 s + 4 q + {0..3} of frame f with one 16-byte load and feeds component c
-  // to MFMA (s, c), whose k index q therefore stands for filter 16 s + 4 q + c.
+  // to MFMA (s, c), whose k index q therefore stands for filter 16 s + 4 q + c.  One image per group of 16 coefficients.
   d.P.clear();
-  if (M % 16 == 0 && K <= 16) {
+  if (M % 16 == 0 && C <= 3) {
     const int S = M / 16;
-    d.P.assign((size_t)S * 4 * 64, 0.f);
-    for (int s = 0; s < S; ++s)
-      for (int c = 0; c < 4; ++c)
-        for (int l = 0; l < 64; ++l) {
-          const int k = l & 15, m = 16 * s + 4 * (l >> 4) + c;
-          if (k < K) d.P[((size_t)s * 4 + c) * 64 + l] = D[(size_t)k * M + m];
-        }
+    d.P.assign((size_t)C * S * 4 * 64, 0.f);
+    for (int g = 0; g < C; ++g)
+      for (int s = 0; s < S; ++s)
+        for (int c = 0; c < 4; ++c)
+          for (int l = 0; l < 64; ++l) {
+            const int k = 16 * g + (l & 15), m = 16 * s + 4 * (l >> 4) + c;
+            if (k < K) d.P[(((size_t)g * S + s) * 4 + c) * 64 + l] = D[(size_t)k * M + m];
+          }
   }
   if (d.P.empty()) d.P.push_back(0.f);
 }
