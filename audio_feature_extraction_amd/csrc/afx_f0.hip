@@ -100,17 +100,33 @@ __global__ __launch_bounds__(64) void k_f0_energy(const float* __restrict__ ysig
   __syncthreads();
   if (lane < E && t0 + lane < T) {
     float e = 0.f;
-    const int base = lane * hop;
     const int nsteps = fp.W + fp.n_tau;
-    for (int n = 0; n < nsteps; ++n) {
-      const int idx = base + n;
-      e = sq_acc(e, S[idx + idx / hop]);
-      if (n < fp.n_tau) H[n * hs + lane] = e;
-      if (n >= fp.W) {
-        const int tau = n - fp.W;
-        float d = e - H[tau * hs + lane];
-        if (fabsf(d) < 1e-6f) d = 0.f;
-        H[tau * hs + lane] = d;
+    // padded index of sample lane * hop + n is lane * (hop + 1) + n + n / hop: n / hop is carried, not divided.
+    // Eight samples (and the eight history values they meet) are fetched before the serial float32 chain touches
+    // them, so the chain costs its additions, not an LDS round trip per step.
+    int sidx = lane * (hop + 1), r = 0;
+    for (int n0 = 0; n0 < nsteps; n0 += 8) {
+      float yv[8], hv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        yv[u] = (n0 + u < nsteps) ? S[sidx] : 0.f;
+        ++sidx;
+        if (++r == hop) { r = 0; ++sidx; }
+        const int tau = n0 + u - fp.W;
+        hv[u] = (tau >= 0 && n0 + u < nsteps) ? H[tau * hs + lane] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int n = n0 + u;
+        if (n < nsteps) {
+          e = sq_acc(e, yv[u]);
+          if (n < fp.n_tau) H[n * hs + lane] = e;
+          if (n >= fp.W) {
+            float d = e - hv[u];
+            if (fabsf(d) < 1e-6f) d = 0.f;
+            H[(n - fp.W) * hs + lane] = d;
+          }
+        }
       }
     }
   }
