@@ -202,6 +202,10 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
   }
   __syncthreads();
 
+  const bool shared_chunks = W == 2 * hop;
+  double carry[RR];
+#pragma unroll
+  for (int r = 0; r < RR; ++r) carry[r] = 0.0;
   for (int fi = 0; fi < kF0FramesPerBlock / 4; ++fi) {
     const int f = wave * (kF0FramesPerBlock / 4) + fi;
     const int t = t0 + f;
@@ -209,16 +213,29 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
     const int64_t slot = cd.frame_base + t;
     const double* F = Y + (size_t)f * hop;
 
-    // ---- autocorrelation acf[tau] = sum_{i=1..W} y[i] y[i + tau]  (what irfft(rfft(y) rfft(y[W:0:-1])) [W:] is)
+    // ---- autocorrelation acf[tau] = sum_{i=1..W} y[i] y[i + tau]  (what irfft(rfft(y) rfft(y[W:0:-1])) [W:] is).
+    // With W = 2 hop a frame is two hop-sized chunks and neighbouring frames share one: the wave keeps the
+    // previous chunk's partial sums and adds one new chunk per frame (5 chunks for its 4 frames instead of 8).
     double acc[RR];
+    auto chunk = [&](const double* base, int len, double (&out)[RR]) {     // out[r] = sum_{i=1..len} base[i] base[i + lane + 64 r]
 #pragma unroll
-    for (int r = 0; r < RR; ++r) acc[r] = 0.0;
+      for (int r = 0; r < RR; ++r) out[r] = 0.0;
 #pragma unroll 4
-    for (int i = 1; i <= ((fp.debug & 4) ? 8 : W); ++i) {
-      const double yi = F[i];
-      const double* q = F + i + lane;
+      for (int i = 1; i <= len; ++i) {
+        const double yi = base[i];
+        const double* q = base + i + lane;
 #pragma unroll
-      for (int r = 0; r < RR; ++r) acc[r] = fma(yi, q[64 * r], acc[r]);
+        for (int r = 0; r < RR; ++r) out[r] = fma(yi, q[64 * r], out[r]);
+      }
+    };
+    if (shared_chunks) {
+      double cur[RR];
+      if (fi == 0) chunk(F, hop, carry);
+      chunk(F + hop, (fp.debug & 4) ? 8 : hop, cur);
+#pragma unroll
+      for (int r = 0; r < RR; ++r) { acc[r] = carry[r] + cur[r]; carry[r] = cur[r]; }
+    } else {
+      chunk(F, (fp.debug & 4) ? 8 : W, acc);
     }
     // ---- difference function d = (e[0] + e[tau]) [float32] - 2 acf [float64]
     const float* Erow = energy + slot * (int64_t)fp.n_tau_pad;
