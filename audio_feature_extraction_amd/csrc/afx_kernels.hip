@@ -1078,7 +1078,7 @@ __host__ __device__ inline Lds2 lds2_layout() {
   L.ex = 0;
   L.pb = L.ex + kWaves * 1024 * 2;
   L.wt = L.pb + round4((513 + kPbPadRows) * kPbStride);
-  L.t2 = L.wt;                              // (the window lives in registers: 16 values per lane, x 0.5)
+  L.t2 = L.wt + 516;                        // half of the (symmetric) window, n = 0 .. 512
   L.t3 = L.t2 + 256;                        // last-pass twiddles of butterfly jb: 7 x 64 float2
   L.tp = L.t3 + 7 * 64 * 2;                 // mel tap weights, quad-padded
   L.mm = L.tp + kMelTapCap;                 // per-filter meta words
@@ -1143,6 +1143,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float2* const EX = reinterpret_cast<float2*>(smem + L.ex) + wave * 1024;
   float* const PB = smem + L.pb;
+  float* const WT = smem + L.wt;
   float2* const T2 = reinterpret_cast<float2*>(smem + L.t2);
   float2* const T3 = reinterpret_cast<float2*>(smem + L.t3);
   float* const TP = smem + L.tp;
@@ -1155,11 +1156,9 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     const float2 v = w1024[m & 511];
     return (m & 512) ? make_float2(-v.x, -v.y) : v;
   };
+  for (int i = tid; i <= N / 2; i += 256) WT[i] = 0.5f * tb.window[i];  // x0.5: the A/B split then needs no 1/2
   if (tid < 128) T2[tid] = W(8 * (tid >> 4) * (tid & 15));              // pass-2 twiddles W_128^(c*r) at [r*16 + c]: a row per r,
                                                                          // so the 16 distinct c of a wave read 128 contiguous bytes
-  float wreg[16];                          // this lane's 16 window values (w[n] = w[N - n]) x 0.5: the A/B split then needs no 1/2
-#pragma unroll
-  for (int u = 0; u < 16; ++u) wreg[u] = 0.5f * tb.window[u < 8 ? lane + 64 * u : (64 - lane) + 64 * (15 - u)];
   const int ja = lane, jb = lane ? 128 - lane : 64;                      // last-pass butterflies of this lane
   float2 tw3a[7];                                                        // butterfly ja: registers; jb: LDS table
 #pragma unroll
@@ -1373,7 +1372,10 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   // window the pair whose frame A is rows y[0..15] and frame B rows y[4..19] (RMS rows come from k_trim_decide)
   auto make_z = [&](const float (&y)[20], float2 (&v)[16], const BlkCtx& c, int flA) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = make_float2(wreg[u] * y[u], wreg[u] * y[u + 4]);
+    for (int u = 0; u < 16; ++u) {
+      const float w = u < 8 ? WT[lane + 64 * u] : WT[(64 - lane) + 64 * (15 - u)];   // w[n] = w[N - n]
+      v[u] = make_float2(w * y[u], w * y[u + 4]);
+    }
   };
 
   // experiment (AFX_DEBUG_SKIP bits 0x1000 / 0x2000): start half of the workgroups ~half a block late
