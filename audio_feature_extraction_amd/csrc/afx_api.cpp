@@ -216,7 +216,6 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
       (rc = upload(pl, reinterpret_cast<const int4*>(t.mel.items.data()), t.mel.items.size() / 4, &items4)) != AFX_OK ||
       (rc = upload(pl, t.taps.taps.data(), t.taps.taps.size(), &pl->dt.mel_taps)) != AFX_OK ||
       (rc = upload(pl, t.taps.meta.data(), t.taps.meta.size(), &pl->dt.mel_meta)) != AFX_OK ||
-      (rc = upload(pl, t.taps.order.data(), t.taps.order.size(), &pl->dt.mel_qorder)) != AFX_OK ||
       (rc = upload(pl, t.dctb.A.data(), t.dctb.A.size(), &pl->dt.dctA)) != AFX_OK ||
       (rc = upload(pl, t.dctb.P.data(), t.dctb.P.size(), &pl->dt.dctP)) != AFX_OK) {
     afx_plan_destroy(pl);
@@ -227,7 +226,6 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
   pl->dt.mel_items = items4;
   for (int w = 0; w < 4; ++w) pl->dt.mel_item_cnt[w] = t.mel.item_cnt[w];
   pl->dt.mel_n_slots = t.mel.n_slots;
-  for (int w = 0; w < 4; ++w) pl->dt.mel_qcnt[w] = t.taps.cnt[w];
   pl->dt.mel_ntaps = t.taps.usable ? (int32_t)t.taps.taps.size() : 0;
   pl->dt.n_groups = t.mel.n_groups;
   kp.rms_sub = frames2_eligible(kp, pl->dt) ? kp.trim_hop / kp.hop : 0;

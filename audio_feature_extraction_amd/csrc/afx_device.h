@@ -57,11 +57,9 @@ struct DevTables {
   const int4* mel_items;  // [4 waves][8 items][2 x int4]: group, b0, nb, role | slot, nslots, 0, 0
   int32_t mel_item_cnt[4];
   int32_t mel_n_slots;    // LDS partial-sum slots in use (0: no group is split)
-  const float* mel_taps;  // k_frames2: quad-padded tap weights
-  const int32_t* mel_meta; // k_frames2: per filter k0 | n4q << 10 | offset << 15
-  const int32_t* mel_qorder; // k_frames2: [4][kMelMaxQuads] quad ids
-  int32_t mel_qcnt[4];
-  int32_t mel_ntaps;      // floats in mel_taps (k_frames2 needs <= kMelTapCap)
+  const float* mel_taps;  // k_frames2: oct-padded tap weights
+  const int32_t* mel_meta; // k_frames2: per filter k0 | n4 << 10 | offset << 15
+  int32_t mel_ntaps;      // floats in mel_taps; 0: tables unusable, generic kernel
   const float* dctA;     // DCT-II rows as MFMA A images
   const float* dctP;     // the same, permuted for k_dct16's 16-byte tile loads (nullptr: not applicable)
   int32_t n_groups;      // ceil(n_mels / 16)

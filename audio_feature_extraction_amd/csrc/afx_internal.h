@@ -31,14 +31,11 @@ struct MelBlocks {
   std::vector<float> koff;      // per (group, row): kmin - kc  (k - kc = koff + 4*blk + q)
 };
 
-// Tap tables for k_frames2's VALU mel stage.  Filters are taken four at a time (a "quad"); the four
-// lane-quarters of a wave split a filter's taps (tap i goes to quarter i % 4), so every filter of a
-// quad is padded with zero weights to the quad's longest tap count (a multiple of 4).
+// Tap tables for k_frames2's mel stage: filters in groups of eight ("octs"), every filter of an oct padded
+// with zero weights to the oct's longest tap count (a multiple of 4).
 struct MelTaps {
-  std::vector<float> taps;        // per quad: 4 filters x (4 * n4q) weights
-  std::vector<int32_t> meta;      // per filter: k0 | n4q << 10 | tap offset << 15
-  std::vector<int32_t> order;     // [4 waves][kMelMaxQuads] quad ids, dealt longest-first
-  int32_t cnt[4] = {0, 0, 0, 0};
+  std::vector<float> taps;        // per oct: 8 filters x (4 * n4) weights
+  std::vector<int32_t> meta;      // per filter: k0 | n4 << 10 | tap offset << 15
   bool usable = false;            // false: the generic kernel is used instead
 };
 

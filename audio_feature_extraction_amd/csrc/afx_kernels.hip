@@ -1067,25 +1067,29 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
 //     last radix-8 pass gives each lane the butterflies j and 128-j, i.e. both Z[k] and Z[N-k];
 //   * schedule 16 x 8 x 8 on one wave (16 points per lane): two LDS exchanges of 8 KB per frame pair,
 //     image XOR-swizzled a ^ ((a>>4)&15) -> every ds_write_b64 / ds_read_b64 conflict-free;
-//   * no staging pass: a lane reads its 16+16 samples straight from global memory (256-B coalesced
-//     rows, re-reads of the 75 % frame overlap are L1/L2 hits), pre-emphasis on the fly with the
-//     predecessor taken from the neighbouring lane (DPP); the next pair's loads fly under the FFT.
-// LDS: exchange images 32 KB + power-spectrum buffer 35 KB + window 4 KB + tables 3 KB = 75 KB.
+//   * no staging pass: a lane fetches 16-byte sample quads straight from global memory and re-cuts them into
+//     rows through the wave's idle exchange image (pre-emphasis with the predecessor read at offset -1 of the
+//     same image); the next block's quads fly under the second pair's FFT and the mel phase;
+//   * the window (x 0.5) sits in 16 registers per lane; the exchange-image slot bases are rebuilt per pair from
+//     an opaque copy of the lane id -- hoisted out of the block loop their XOR variants cost 30 registers, and
+//     the kernel's register budget decides whether the other streams' small kernels fit beside it;
+//   * mel: filters in octs, a lane walks one filter for the two frames of a pair (8-byte PB reads, packed FMAs).
+// LDS: exchange images 32 KB + power-spectrum buffer 36.3 KB + twiddle tables 4.5 KB + mel taps 5.1 KB = 78 KB.
 // ---------------------------------------------------------------------------
-struct Lds2 { int ex, pb, wt, t2, t3, tp, mm, total; };     // float offsets
-__host__ __device__ inline Lds2 lds2_layout() {
+constexpr int kPb2Stride = 18;  // k_frames2's power-spectrum rows: 8 frame pairs + 1 pad pair.  Even, so that a pair is one
+                                // aligned 8-byte access; 18 l mod 32 is a permutation of the even banks for 16 lanes
+struct Lds2 { int ex, pb, t2, t3, tp, total; };         // float offsets
+__host__ __device__ inline Lds2 lds2_layout(int ntaps) {
   Lds2 L;
   L.ex = 0;
   L.pb = L.ex + kWaves * 1024 * 2;
-  L.wt = L.pb + round4((513 + kPbPadRows) * kPbStride);
-  L.t2 = L.wt + 516;                        // half of the (symmetric) window, n = 0 .. 512
+  L.t2 = L.pb + round4((513 + kPbPadRows) * kPb2Stride);    // pass-2 twiddles: 128 float2
   L.t3 = L.t2 + 256;                        // last-pass twiddles of butterfly jb: 7 x 64 float2
-  L.tp = L.t3 + 7 * 64 * 2;                 // mel tap weights, quad-padded
-  L.mm = L.tp + kMelTapCap;                 // per-filter meta words
-  L.total = L.mm + 128;
+  L.tp = L.t3 + 7 * 64 * 2;                 // mel tap weights, oct-padded (sized by the plan's table)
+  L.total = L.tp + round4(ntaps);
   return L;
 }
-size_t frames2_lds_bytes() { return (size_t)lds2_layout().total * sizeof(float); }
+size_t frames2_lds_bytes(int ntaps) { return (size_t)lds2_layout(ntaps).total * sizeof(float); }
 
 // radix-16 DFT in registers as 4 x 4 with the W16 twiddles as constants
 __device__ __forceinline__ void dft16(float2* x) {
@@ -1116,7 +1120,9 @@ __device__ __forceinline__ void dft16(float2* x) {
   }
 }
 
-template <int FMT, bool STAMP>
+// DBG: the timing-only ablation switches (AFX_DEBUG_SKIP) are compiled in; the production instantiation does not
+// carry the flag word or its branches
+template <int FMT, bool STAMP, bool DBG>
 __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ samples,
                                                     ClipInfo* __restrict__ info,
                                                     const BlockDesc* __restrict__ blocks, int nblocks,
@@ -1137,28 +1143,28 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     }
   };
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Lds2 L = lds2_layout();
+  const Lds2 L = lds2_layout(tb.mel_ntaps);
   const int hop = kp.hop, M = kp.n_mels;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float2* const EX = reinterpret_cast<float2*>(smem + L.ex) + wave * 1024;
   float* const PB = smem + L.pb;
-  float* const WT = smem + L.wt;
   float2* const T2 = reinterpret_cast<float2*>(smem + L.t2);
   float2* const T3 = reinterpret_cast<float2*>(smem + L.t3);
   float* const TP = smem + L.tp;
-  int* const MM = reinterpret_cast<int*>(smem + L.mm);
 
   // ---- once per workgroup: tables -> LDS, per-lane twiddles -> registers
-  for (int i = tid; i < kPbPadRows * kPbStride; i += 256) PB[NB * kPbStride + i] = 0.f;
+  for (int i = tid; i < kPbPadRows * kPb2Stride; i += 256) PB[NB * kPb2Stride + i] = 0.f;
   const float2* w1024 = reinterpret_cast<const float2*>(tb.post);      // exp(-2 pi i k / 1024), k < 512
   auto W = [&](int m) {                                                  // W_1024^m, 0 <= m < 1024
     const float2 v = w1024[m & 511];
     return (m & 512) ? make_float2(-v.x, -v.y) : v;
   };
-  for (int i = tid; i <= N / 2; i += 256) WT[i] = 0.5f * tb.window[i];  // x0.5: the A/B split then needs no 1/2
   if (tid < 128) T2[tid] = W(8 * (tid >> 4) * (tid & 15));              // pass-2 twiddles W_128^(c*r) at [r*16 + c]: a row per r,
                                                                          // so the 16 distinct c of a wave read 128 contiguous bytes
+  float wreg[16];                          // this lane's 16 window values (w[n] = w[N - n]) x 0.5: the A/B split then needs no 1/2
+#pragma unroll
+  for (int u = 0; u < 16; ++u) wreg[u] = 0.5f * tb.window[u < 8 ? lane + 64 * u : (64 - lane) + 64 * (15 - u)];
   const int ja = lane, jb = lane ? 128 - lane : 64;                      // last-pass butterflies of this lane
   float2 tw3a[7];                                                        // butterfly ja: registers; jb: LDS table
 #pragma unroll
@@ -1168,19 +1174,14 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     for (int r = 1; r < 8; ++r) T3[(r - 1) * 64 + tid] = W(jb * r);
   }
   for (int i = tid; i < tb.mel_ntaps; i += 256) TP[i] = tb.mel_taps[i];
-  if (tid < ((M + 3) & ~3)) MM[tid] = tb.mel_meta[tid];
   // exchange-image slots (see header): all per-lane bases
-  const int sA1 = 16 * lane + (lane & 15);
-  const int sR1 = lane ^ (lane >> 4);
-  const int sW2a = 128 * (lane >> 4) + ((lane & 15) ^ (((lane >> 4) & 1) << 3));
-  const int sW2b = sW2a + 512;                                           // butterfly j = lane + 64: x = (lane>>4) + 4, same parity
-  const int sRa = ja ^ ((ja >> 4) & 7), sRb = jb ^ ((jb >> 4) & 7);
 
-  // mel quads of this wave: quad NQ-1 - (4*it + (it odd ? 3 - wave : wave)), it = 0..7 -- a snake over the quads
-  // from the widest down, which balances the four waves because tap counts grow with the quad index.
-  // Computed where used from `wave` (never kept per quad: that would cost two dozen scalar registers).
-  const int NQ = (M + 3) >> 2;
-  auto quad_of = [&](int wv, int it) { return NQ - 1 - (4 * it + ((it & 1) ? 3 - wv : wv)); };
+  // mel octs (8 filters) of this wave: oct NO-1 - (4*it + (it odd ? 3 - wave : wave)), it = 0..3 -- a snake over the
+  // octs from the widest down, which balances the four waves because tap counts grow with the filter index.
+  // Computed where used from `wave` (never kept per oct: that would cost scalar registers).
+  constexpr int kOctsPerWave = kMelMaxOcts / 4;
+  const int NO = (M + 7) >> 3;
+  auto oct_of = [&](int wv, int it) { return NO - 1 - (4 * it + ((it & 1) ? 3 - wv : wv)); };
   const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
   const float b1 = kp.preemph_b1;
 
@@ -1194,14 +1195,14 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     auto rl64 = [&](int i) { return (int64_t)(((uint64_t)(uint32_t)rl(i + 1) << 32) | (uint32_t)rl(i)); };
     c.sample_base = rl64(0); c.frame_slot = rl64(2); c.clip_off = rl64(4);
     c.keep_lo = rl(6); c.keep_hi = rl(7); c.have_lo = rl(8); c.have_hi = rl(9);
-    c.clip = rl(10); c.t0 = rl(11); c.T = rl(12);
+    c.clip = rl(10); c.t0 = 0; c.T = rl(12) - rl(11);     // only T - t0 (frames left from this block on) is used here
     c.active = (b < nblocks) && rl(13) != 0;
     c.interior = false;
     return c;
   };
 
   // deferred log-mel stores (see k_frames)
-  float lmh[kMelMaxQuads];
+  float2 lmh[kOctsPerWave];                 // log-mel of this lane's filter for its two frames, per oct
   bool pend = false;
   float pend_lmax = -INFINITY;
   int64_t pend_slot = 0;
@@ -1211,16 +1212,19 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     pend = false;
     int lane_f = lane;
     asm volatile("" : "+v"(lane_f));
-    const int f16 = lane_f & 15, q4 = lane_f >> 4;
-    const bool valid = (pend_t0 + f16) < pend_T;
-    float* tile = logmel + pend_slot * (int64_t)M + f16 * 4 + q4;
+    const int fp2 = (lane_f & 7) * 2, j8 = lane_f >> 3;               // frames fp2, fp2 + 1; filter j8 of the oct
+    const bool v0 = (pend_t0 + fp2) < pend_T, v1 = (pend_t0 + fp2 + 1) < pend_T;
+    // tile layout [mel/4][frame][mel%4]
+    float* tile = logmel + pend_slot * (int64_t)M + (j8 >> 2) * 64 + fp2 * 4 + (j8 & 3);
     int wv = wave;
     asm volatile("" : "+s"(wv));
-    // tile layout [mel/4][frame][mel%4]: a quad is 64 consecutive floats, lane (f16, q4) owns filter 4*qd + q4
 #pragma unroll
-    for (int i = 0; i < kMelMaxQuads; ++i) {
-      const int qd = quad_of(wv, i);
-      if (qd >= 0 && valid && qd * 4 + q4 < M) tile[qd * 64] = lmh[i];
+    for (int i = 0; i < kOctsPerWave; ++i) {
+      const int o = oct_of(wv, i);
+      if (o >= 0 && o * 8 + j8 < M) {
+        if (v0) tile[o * 128] = lmh[i].x;
+        if (v1) tile[o * 128 + 4] = lmh[i].y;
+      }
     }
     const float mx = wave_max(pend_lmax);
     if (lane_f == 0 && mx > -INFINITY) atomicMax(&info[pend_clip].lmax_ord, f2ord(mx));
@@ -1259,7 +1263,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   };
   auto issue_rows = [&](const BlkCtx& c) {             // first pair of block c: rows 0..19
     rows_raw = c.active && pair_is_interior(c, wave * 4);
-    if (rows_raw && !(kp.flags & 0x100)) {             // 0x100: timing-only ablation (stale registers)
+    if (rows_raw && !(DBG && (kp.flags & 0x100))) {             // 0x100: timing-only ablation (stale registers)
       const int64_t ba = c.sample_base + (int64_t)(wave * 4) * hop;
 #pragma unroll
       for (int ch = 0; ch < 5; ++ch) qrows[ch] = quad_ld(ba + 4 * lane + 256 * ch);
@@ -1268,7 +1272,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   };
   auto issue_inc = [&](const BlkCtx& c) {              // second pair: its 8 new rows (20..27 of the window)
     inc_raw = pair_is_interior(c, wave * 4 + 2);
-    if (inc_raw && !(kp.flags & 0x100)) {
+    if (inc_raw && !(DBG && (kp.flags & 0x100))) {
       const int64_t ba = c.sample_base + (int64_t)(wave * 4) * hop + 64 * 20;
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) qinc[ch] = quad_ld(ba + 4 * lane + 256 * ch);
@@ -1308,6 +1312,15 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   // ---- one pair: z = w*yA + i*w*yB -> 1024-point FFT -> |X_A|^2, |X_B|^2 into PB columns flA, flA+1
   auto fft_pair = [&](float2 (&v)[16], int flA) {
     stamp(ST_STAGE);
+    // exchange-image slots, rebuilt per pair from an opaque copy of the lane id: kept across the block loop they
+    // would hold five registers that the frame kernel's 224-register budget does not have
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int sA1 = 16 * ln + (ln & 15);
+    const int sR1 = ln ^ (ln >> 4);
+    const int sW2a = 128 * (ln >> 4) + ((ln & 15) ^ (((ln >> 4) & 1) << 3));
+    const int jbl = ln ? 128 - ln : 64;
+    const int sRa = ln ^ ((ln >> 4) & 7), sRb = jbl ^ ((jbl >> 4) & 7);
     // pass 1: radix 16 (no twiddles), exchange
     dft16(v);
 #pragma unroll
@@ -1329,7 +1342,8 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
       for (int r = 1; r < 8; ++r) { xa[r] = cmul(xa[r], t2v[r]); xb[r] = cmul(xb[r], t2v[r]); }
       dft<8>(xa); dft<8>(xb);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) { EX[sW2a ^ (17 * r)] = xa[r]; EX[sW2b ^ (17 * r)] = xb[r]; }
+      // butterfly j = lane + 64 sits 512 slots further (x = (lane >> 4) + 4, same parity; 17 r and sW2a are < 512)
+      for (int r = 0; r < 8; ++r) { EX[sW2a ^ (17 * r)] = xa[r]; EX[(sW2a ^ (17 * r)) + 512] = xb[r]; }
     }
     AFX_CBARRIER();
     stamp(ST_PREFETCH);
@@ -1350,8 +1364,8 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     float* const pcol = PB + flA;
     auto power = [&](float2 za, float2 zb, int bin) {
       const float ar = za.x + zb.x, ai = za.y - zb.y, br = za.y + zb.y, bi = za.x - zb.x;
-      pcol[bin * kPbStride] = ar * ar + ai * ai;           // |X_A[bin]|^2
-      pcol[bin * kPbStride + 1] = br * br + bi * bi;       // |X_B[bin]|^2
+      *reinterpret_cast<float2*>(pcol + bin * kPb2Stride) =        // |X_A[bin]|^2, |X_B[bin]|^2: flA is even
+          make_float2(ar * ar + ai * ai, br * br + bi * bi);
     };
     auto sel = [&](float2 a, float2 b) { return make_float2(l0 ? b.x : a.x, l0 ? b.y : a.y); };
     power(sel(A[0], A[1]), sel(B[7], A[7]), l0 ? 128 : lane);
@@ -1363,8 +1377,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     power(sel(A[6], B[3]), sel(B[1], B[4]), l0 ? 448 : 256 - lane);
     power(sel(A[7], A[0]), sel(B[0], A[0]), l0 ? 0 : 128 - lane);
     if (l0) {                                              // Nyquist bin from Z[512] = A[4]
-      pcol[512 * kPbStride] = 4.f * A[4].x * A[4].x;
-      pcol[512 * kPbStride + 1] = 4.f * A[4].y * A[4].y;
+      *reinterpret_cast<float2*>(pcol + 512 * kPb2Stride) = make_float2(4.f * A[4].x * A[4].x, 4.f * A[4].y * A[4].y);
     }
     AFX_CBARRIER();
     stamp(ST_FFT);
@@ -1372,14 +1385,11 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   // window the pair whose frame A is rows y[0..15] and frame B rows y[4..19] (RMS rows come from k_trim_decide)
   auto make_z = [&](const float (&y)[20], float2 (&v)[16], const BlkCtx& c, int flA) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const float w = u < 8 ? WT[lane + 64 * u] : WT[(64 - lane) + 64 * (15 - u)];   // w[n] = w[N - n]
-      v[u] = make_float2(w * y[u], w * y[u + 4]);
-    }
+    for (int u = 0; u < 16; ++u) v[u] = make_float2(wreg[u] * y[u], wreg[u] * y[u + 4]);
   };
 
   // experiment (AFX_DEBUG_SKIP bits 0x1000 / 0x2000): start half of the workgroups ~half a block late
-  if (((kp.flags & 0x1000) && blockIdx.x >= gridDim.x / 2) || ((kp.flags & 0x2000) && (blockIdx.x & 1))) {
+  if (DBG && (((kp.flags & 0x1000) && blockIdx.x >= gridDim.x / 2) || ((kp.flags & 0x2000) && (blockIdx.x & 1)))) {
     for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);
   }
   BlkCtx cur = resolve(fetch_desc(blockIdx.x), blockIdx.x);
@@ -1392,7 +1402,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     const BlkCtx nxt = resolve(dnext, b + gridDim.x);
     dnext = fetch_desc(b + 2 * gridDim.x);
 
-    if (cur.active && !(kp.flags & 0x200)) {
+    if (cur.active && !(DBG && (kp.flags & 0x200))) {
       const int fl0 = wave * 4;
       float2 v[16];
       // ---- pair 0 (frames fl0, fl0+1): rows 0..19
@@ -1445,69 +1455,60 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
     stamp(ST_BAR2);
 
     // ---- mel filterbank + dB on the vector pipe.  A mel row touches only its own ~2..60 bins, so as a matrix
-    // product it is >85 % zeros even block-sparse; here every multiply is a real tap.  Filters are taken four
-    // at a time (a quad): lane (f16, q4) walks the taps of filter 4*qd + q4 for frame f16 -- one P read, one
-    // weight read (broadcast within the quarter) and one FMA per tap, 8 taps in flight ahead of the FMAs.
-    const bool mel_on = cur.active && !(kp.flags & 0x400);
+    // product it is >85 % zeros even block-sparse; here every multiply is a real tap.  Filters are taken eight
+    // at a time (an oct): lane (pair fp, j) walks the taps of filter 8*oct + j for the frames 2fp and 2fp+1 -- one
+    // 8-byte P read (both frames), a quarter of a 16-byte weight read (shared by the oct's 8 lanes of that filter)
+    // and one packed FMA per tap.
+    const bool mel_on = cur.active && !(DBG && (kp.flags & 0x400));
     if (mel_on) {
       int lane_m = lane;
       asm volatile("" : "+v"(lane_m));
-      const int f16 = lane_m & 15, q4 = lane_m >> 4;
-      const bool valid = (cur.t0 + f16) < cur.T;
+      const int fp2 = (lane_m & 7) * 2, j8 = lane_m >> 3;
+      const bool v0 = (cur.t0 + fp2) < cur.T, v1 = (cur.t0 + fp2 + 1) < cur.T;
       float lmax = -INFINITY;
       int wv = wave;
       asm volatile("" : "+s"(wv));
-      int mw[kMelMaxQuads];
+      int mw[kOctsPerWave];
 #pragma unroll
-      for (int it = 0; it < kMelMaxQuads; ++it) { const int qd = quad_of(wv, it); mw[it] = qd >= 0 ? MM[4 * qd + q4] : 0; }
+      for (int it = 0; it < kOctsPerWave; ++it) { const int o = oct_of(wv, it); mw[it] = o >= 0 ? tb.mel_meta[8 * o + j8] : 0; }
 #pragma unroll
-      for (int it = 0; it < kMelMaxQuads; ++it) {
-        const int qd = quad_of(wv, it);
-        if (qd >= 0) {
-          const int n4 = __builtin_amdgcn_readfirstlane(mw[it] >> 10) & 31;   // same for the four filters of a quad
-          const float* p = PB + (mw[it] & 1023) * kPbStride + f16;
+      for (int it = 0; it < kOctsPerWave; ++it) {
+        const int o = oct_of(wv, it);
+        if (o >= 0) {
+          const int n4 = __builtin_amdgcn_readfirstlane(mw[it] >> 10) & 31;   // same for the eight filters of an oct, >= 1
+          const float* p = PB + (mw[it] & 1023) * kPb2Stride + fp2;
           const float4* w = reinterpret_cast<const float4*>(TP + (mw[it] >> 15));
-          float a0 = 0.f, a1 = 0.f;
-          float x[8], xn[8];
-          float4 c0, c1, cn0, cn1;
-          auto ld8 = [&](float (&xx)[8], float4& ca, float4& cb) {
+          float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
+          auto ld = [&](float2 (&xx)[4], float4& c, int bi) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) xx[t] = p[t * kPbStride];
-            ca = w[0]; cb = w[1];
+            for (int t = 0; t < 4; ++t) xx[t] = *reinterpret_cast<const float2*>(p + (4 * bi + t) * kPb2Stride);
+            c = w[bi];
           };
-          auto fm8 = [&]() {
-            a0 = fmaf(c0.x, x[0], a0); a1 = fmaf(c0.y, x[1], a1); a0 = fmaf(c0.z, x[2], a0); a1 = fmaf(c0.w, x[3], a1);
-            a0 = fmaf(c1.x, x[4], a0); a1 = fmaf(c1.y, x[5], a1); a0 = fmaf(c1.z, x[6], a0); a1 = fmaf(c1.w, x[7], a1);
+          auto fm = [&](const float2 (&xx)[4], const float4& c) {
+            a0.x = fmaf(c.x, xx[0].x, a0.x); a0.y = fmaf(c.x, xx[0].y, a0.y);
+            a1.x = fmaf(c.y, xx[1].x, a1.x); a1.y = fmaf(c.y, xx[1].y, a1.y);
+            a0.x = fmaf(c.z, xx[2].x, a0.x); a0.y = fmaf(c.z, xx[2].y, a0.y);
+            a1.x = fmaf(c.w, xx[3].x, a1.x); a1.y = fmaf(c.w, xx[3].y, a1.y);
           };
-          const int nfull = n4 >> 1;
-          if (nfull > 0) {
-            ld8(x, c0, c1);
-            for (int bq = 1; bq < nfull; ++bq) {
-              p += 8 * kPbStride; w += 2;
-              ld8(xn, cn0, cn1);
-              fm8();
-#pragma unroll
-              for (int t = 0; t < 8; ++t) x[t] = xn[t];
-              c0 = cn0; c1 = cn1;
-            }
-            if (n4 & 1) {
-#pragma unroll
-              for (int t = 0; t < 4; ++t) xn[t] = p[(8 + t) * kPbStride];
-              cn0 = w[2];
-              fm8();
-              a0 = fmaf(cn0.x, xn[0], a0); a1 = fmaf(cn0.y, xn[1], a1); a0 = fmaf(cn0.z, xn[2], a0); a1 = fmaf(cn0.w, xn[3], a1);
-            } else {
-              fm8();
-            }
-          } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) x[t] = p[t * kPbStride];
-            c0 = w[0];
-            a0 = fmaf(c0.x, x[0], a0); a1 = fmaf(c0.y, x[1], a1); a0 = fmaf(c0.z, x[2], a0); a1 = fmaf(c0.w, x[3], a1);
+          float2 x0[4], x1[4];
+          float4 c0, c1;
+          ld(x0, c0, 0);
+          int bi = 1;
+          for (; bi + 1 < n4; bi += 2) {                    // two batches per turn, the next pair in flight
+            ld(x1, c1, bi);
+            fm(x0, c0);
+            ld(x0, c0, bi + 1);
+            fm(x1, c1);
           }
-          const float Lv = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, a0 + a1));
-          lmh[it] = Lv;
-          if (valid && qd * 4 + q4 < M) lmax = fmaxf(lmax, Lv);
+          if (bi < n4) { ld(x1, c1, bi); fm(x0, c0); fm(x1, c1); }
+          else fm(x0, c0);
+          const float L0 = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, a0.x + a1.x));
+          const float L1 = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, a0.y + a1.y));
+          lmh[it] = make_float2(L0, L1);
+          if (o * 8 + j8 < M) {
+            if (v0) lmax = fmaxf(lmax, L0);
+            if (v1) lmax = fmaxf(lmax, L1);
+          }
         }
       }
       pend = true;
@@ -1779,7 +1780,7 @@ hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* in
 
 bool frames2_eligible(const KParams& kp, const DevTables& tb) {
   const int per = kp.hop > 0 ? kp.trim_hop / kp.hop : 0;
-  return kp.n_fft == 1024 && kp.hop == 256 && tb.mel_ntaps > 0 && tb.mel_ntaps <= kMelTapCap && kp.n_mels <= 128 &&
+  return kp.n_fft == 1024 && kp.hop == 256 && tb.mel_ntaps > 0 && frames2_lds_bytes(tb.mel_ntaps) <= 80 * 1024 && kp.n_mels <= 128 &&
          kp.trim_hop % kp.hop == 0 && per >= 1 && per <= 4 && !getenv("AFX_GENERIC_1024");
 }
 
@@ -1810,7 +1811,7 @@ static hipError_t launch_frames_t(hipStream_t s, const void* samples, ClipInfo* 
   return hipGetLastError();
 }
 
-template <int FMT, bool STAMP>
+template <int FMT, bool STAMP, bool DBG>
 static hipError_t launch_frames2_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
                                    int nblocks, const DevTables& tb, const KParams& kp, float* logmel,
                                    float* rms_rows, int grid, unsigned long long* stamps) {
@@ -1819,13 +1820,13 @@ static hipError_t launch_frames2_t(hipStream_t s, const void* samples, ClipInfo*
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames2<FMT, STAMP>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames2<FMT, STAMP, DBG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((k_frames2<FMT, STAMP>), dim3(grid), dim3(256), frames2_lds_bytes(), s, samples, info, blocks,
-                     nblocks, tb, kp, logmel, rms_rows, stamps);
+  hipLaunchKernelGGL((k_frames2<FMT, STAMP, DBG>), dim3(grid), dim3(256), frames2_lds_bytes(tb.mel_ntaps), s, samples, info,
+                     blocks, nblocks, tb, kp, logmel, rms_rows, stamps);
   return hipGetLastError();
 }
 
@@ -1833,11 +1834,14 @@ hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
                          const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
                          float* logmel, float* rms_rows, int grid, unsigned long long* stamps) {
   if (frames2_eligible(kp, tb) && kp.rms_sub > 0) {
-    if (kp.fmt == AFX_FMT_S16)
-      return stamps ? launch_frames2_t<AFX_FMT_S16, true>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps)
-                    : launch_frames2_t<AFX_FMT_S16, false>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
-    return stamps ? launch_frames2_t<AFX_FMT_F32, true>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps)
-                  : launch_frames2_t<AFX_FMT_F32, false>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
+    const bool dbg = (kp.flags & 0x7f00) != 0 || stamps != nullptr;     // ablation switches / stamps: diagnostic instantiations
+#define AFX_F2(FMT)                                                                                              \
+    (stamps ? launch_frames2_t<FMT, true, true>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps)   \
+            : dbg ? launch_frames2_t<FMT, false, true>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps)  \
+                  : launch_frames2_t<FMT, false, false>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps))
+    if (kp.fmt == AFX_FMT_S16) return AFX_F2(AFX_FMT_S16);
+    return AFX_F2(AFX_FMT_F32);
+#undef AFX_F2
   }
   switch (kp.n_fft) {
     case 256:  return launch_frames_t<256>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);

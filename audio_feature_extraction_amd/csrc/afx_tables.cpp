@@ -160,47 +160,35 @@ static void build_mel_blocks(const afx_params& p, const std::vector<float>& W,
 }
 
 static void build_mel_taps(const afx_params& p, const std::vector<float>& W, MelTaps& t) {
-  const int M = p.n_mels, NB = p.n_fft / 2 + 1, NQ = (M + 3) / 4;
-  t.usable = true;
-  t.taps.clear(); t.meta.assign((size_t)NQ * 4, 0); t.order.assign((size_t)4 * kMelMaxQuads, 0);
-  std::vector<int> n4q(NQ, 0);
-  for (int qd = 0; qd < NQ; ++qd) {
-    int first[4], nnz[4];
-    for (int j = 0; j < 4; ++j) {
-      const int m = 4 * qd + j;
+  // Filters are taken eight at a time (an "oct"): in k_frames2's mel walk lane (pair, j) accumulates filter
+  // 8 * oct + j for the two frames of a frame pair, so the eight filters of an oct are padded with zero weights
+  // to the oct's longest tap count (a multiple of 4).
+  const int M = p.n_mels, NB = p.n_fft / 2 + 1, NO = (M + 7) / 8;
+  t.usable = NO <= kMelMaxOcts;
+  t.taps.clear(); t.meta.assign((size_t)NO * 8, 0);
+  for (int o = 0; o < NO; ++o) {
+    int first[8], nnz[8], n4 = 1;                      // the kernel always accumulates the first batch
+    for (int j = 0; j < 8; ++j) {
+      const int m = 8 * o + j;
       first[j] = 0; nnz[j] = 0;
       if (m >= M) continue;
       int f = -1, l = -1;
       for (int k = 0; k < NB; ++k) if (W[(size_t)m * NB + k] != 0.f) { if (f < 0) f = k; l = k; }
       if (f >= 0) { first[j] = f; nnz[j] = l - f + 1; }
-      n4q[qd] = std::max(n4q[qd], (nnz[j] + 3) / 4);
+      n4 = std::max(n4, (nnz[j] + 3) / 4);
     }
-    n4q[qd] = std::max(n4q[qd], 1);            // the kernel always accumulates the first batch
-    for (int j = 0; j < 4; ++j)      // the padded taps of every filter must stay inside the spectrum buffer's pad rows
-      if (first[j] + 4 * n4q[qd] - 1 > NB + kPbPadRows - 1) t.usable = false;
-    for (int j = 0; j < 4; ++j) {
-      const int m = 4 * qd + j;
+    for (int j = 0; j < 8; ++j) {
+      // the padded taps of every filter must stay inside the spectrum buffer's pad rows
+      if (first[j] + 4 * n4 - 1 > NB + kPbPadRows - 1) t.usable = false;
+      const int m = 8 * o + j;
       const int woff = (int)t.taps.size();
-      t.meta[m] = first[j] | (n4q[qd] << 10) | (woff << 15);
-      for (int i = 0; i < 4 * n4q[qd]; ++i)
+      if (n4 > 31 || woff >= (1 << 16)) t.usable = false;
+      t.meta[m] = first[j] | (n4 << 10) | (woff << 15);
+      for (int i = 0; i < 4 * n4; ++i)
         t.taps.push_back((m < M && i < nnz[j]) ? W[(size_t)m * NB + first[j] + i] : 0.f);
     }
   }
   if (t.taps.empty()) t.taps.push_back(0.f);
-  // longest-processing-time-first over the 4 waves
-  std::vector<int> idx(NQ);
-  for (int i = 0; i < NQ; ++i) idx[i] = i;
-  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return n4q[a] > n4q[b]; });
-  int load[4] = {0, 0, 0, 0};
-  for (int w = 0; w < 4; ++w) t.cnt[w] = 0;
-  for (int qd : idx) {
-    int best = -1;
-    for (int w = 0; w < 4; ++w)
-      if (t.cnt[w] < kMelMaxQuads && (best < 0 || load[w] < load[best])) best = w;
-    if (best < 0) { t.usable = false; break; } // more than 32 quads: k_frames2 is not used (n_mels > 128)
-    t.order[(size_t)best * kMelMaxQuads + t.cnt[best]++] = qd;
-    load[best] += n4q[qd] + 3;                 // + per-quad overhead
-  }
 }
 
 static void build_dct_blocks(const afx_params& p, const std::vector<float>& D, DctBlocks& d) {
