@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(256) void k_dct(const ClipDesc* __restrict__ clips,
 // k_dct16<NCG>: the same for n_mels % 16 == 0 and n_mfcc <= 16 NCG <= 48 (the reference's 128 / 13).  A wave takes kDctTiles
 // tiles; lane (f, q) fetches filters 16 s + 4 q + {0..3} of frame f with one 16-byte load (a wave-load is 1 KB
 // contiguous), all loads of its tiles issued before the first use; the DCT matrix sits in registers.
-constexpr int kDctTiles = 2;
+constexpr int kDctTiles = 1;
 template <int NCG>
 __global__ __launch_bounds__(256) void k_dct16(const ClipDesc* __restrict__ clips,
                                                const ClipInfo* __restrict__ info,
