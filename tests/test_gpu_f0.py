@@ -157,3 +157,27 @@ def test_f0_random_mixtures(plan):
         fracs.append(same.mean())
         assert same.mean() >= 0.9, (i, same.mean(), np.flatnonzero(~same)[:12])
     assert np.mean(fracs) >= 0.98 and np.median(fracs) == 1.0, fracs
+
+
+def test_f0_batch_is_clipwise_independent(plan):
+    """Size-independent properties at batch scale: a clip's result does not depend on its neighbours, its position
+    in the batch or the chunking of the workspace (every clip twice, shuffled; one clip also on its own)."""
+    rng = np.random.default_rng(3)
+    base = [voiced_tone(float(rng.uniform(90, 600)), float(rng.uniform(0.4, 2.5)), vib=0.01, seed=i) for i in range(24)]
+    base += [make_clip(400 + i, SR, float(rng.uniform(0.5, 2.0)), speechy=bool(i & 1)) for i in range(8)]
+    order = rng.permutation(2 * len(base))
+    clips = [base[k % len(base)] for k in order]
+    out, f0 = run(plan, clips, flags=N.FLAG_PREEMPH | N.FLAG_TRIM)
+    assert (out["status"] == 0).all()
+    first = {}
+    for pos, k in enumerate(order):
+        b = int(k % len(base))
+        if b in first:
+            np.testing.assert_array_equal(out["stats"][pos], out["stats"][first[b]])
+            np.testing.assert_array_equal(f0[pos], f0[first[b]])
+        else:
+            first[b] = pos
+    solo, f0s = run(plan, [base[5]], flags=N.FLAG_PREEMPH | N.FLAG_TRIM)
+    np.testing.assert_array_equal(solo["stats"][0], out["stats"][first[5]])
+    assert np.isfinite(out["stats"]).all() and (out["stats"][:, 2] >= 0).all() and (out["stats"][:, 2] <= 1).all()
+    np.testing.assert_allclose(out["stats"][:, 2] + out["stats"][:, 3], 1.0, atol=1e-15)
