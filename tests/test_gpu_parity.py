@@ -192,3 +192,19 @@ def test_linearity_of_rms_and_shift_of_mfcc(plans):
     d = b["frames"][0]["mfcc"] - a["frames"][0]["mfcc"]
     np.testing.assert_allclose(d[0], 20 * np.log10(0.5) * np.sqrt(128), rtol=1e-5)
     assert np.abs(d[1:]).max() < 2e-3
+
+
+@pytest.mark.parametrize("n_mels", [40, 100, 64])
+def test_other_mel_counts_on_the_tuned_kernel(ctx, n_mels):
+    """n_mels that are not a multiple of 8 leave the last filter oct partly empty (1024/256 path)."""
+    from oracle import cpu_ref as R
+    plan = N.Plan(ctx, N.make_params(22050, 1024, 256, 13, n_mels, "hamming", 0.97))
+    try:
+        y = make_clip(31, 22050, 1.2, speechy=True)
+        out = run_one(plan, y)
+        assert out["status"][0] == 0
+        ref = R.extract_stats(y, sr=22050, frame_length=1024, hop_length=256, n_mfcc=13, n_mels=n_mels, return_frames=True)
+        check_frames(out["frames"][0], ref, f"mels{n_mels}")
+        check_stats(out["stats"][0], ref, 13, f"mels{n_mels}")
+    finally:
+        plan.close()
