@@ -199,11 +199,21 @@ def main() -> None:
             return
         # lanes that start together stay in lockstep (their frame kernels co-run and finish together); a start
         # offset of 1/S of a lane's step keeps one lane's frame kernel over the others' small kernels
-        th = [threading.Thread(target=lane_steps, args=(ln, k, i * stagger[0])) for i, ln in enumerate(lanes)]
+        errs = []
+
+        def guarded(ln, k, delay):
+            try:
+                lane_steps(ln, k, delay)
+            except BaseException as e:      # a lane that dies must fail the run, not shorten it
+                errs.append(e)
+
+        th = [threading.Thread(target=guarded, args=(ln, k, i * stagger[0])) for i, ln in enumerate(lanes)]
         for t in th:
             t.start()
         for t in th:
             t.join()
+        if errs:
+            raise errs[0]
 
     def fence():
         torch.cuda.synchronize()
