@@ -57,6 +57,19 @@ def main():
             rec[k + "_f64"] = np.asarray(b[k], np.float64)
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
         print(name, "frames", a["mfcc"].shape[1], "trim", a["trim"])
+    # extract_f0 (oracle/pyin_ref.py): f0 track, voicing probability and the four statistics of the
+    # preprocessed signal (feature_extractor.py:195 feeds y_processed)
+    from oracle import pyin_ref as P  # noqa: E402
+    for name, idx, secs, speechy in (("f0_plain", 110, 0.8, False), ("f0_speechy", 111, 1.2, True)):
+        y = make_clip(idx, 22050, secs, speechy=speechy)
+        yp, _ = R.preprocess_audio(y)
+        f0, voiced, vp = P.pyin(yp, sr=22050, frame_length=1024, hop_length=256)
+        st = P.extract_f0(yp, 22050, 1024, 256)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"),
+                            params=np.array([22050, 1024, 256, idx, int(speechy)], np.int64), seconds=np.float64(secs),
+                            y_head=y[:16], f0=f0, voiced_prob=vp,
+                            stats=np.array([st["f0_mean"], st["f0_std"], st["f0_missing_rate"], st["f0_quality"]]))
+        print(name, "frames", f0.size, "voiced", float(voiced.mean()))
 
 
 if __name__ == "__main__":

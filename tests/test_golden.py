@@ -9,7 +9,8 @@ import pytest
 from audio_feature_extraction_amd.synth import make_clip
 from oracle import cpu_ref as R
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cfg*.npz")))
+GOLDEN_F0 = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "f0_*.npz")))
 STAT_KEYS = ("mfcc_mean", "mfcc_std", "mfcc_delta_mean", "mfcc_delta2_mean",
              "energy_mean", "energy_std", "energy_range")
 
@@ -22,7 +23,7 @@ def _load(path):
 
 
 def test_fixtures_present():
-    assert len(GOLDEN) == 6
+    assert len(GOLDEN) == 6 and len(GOLDEN_F0) == 2
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
@@ -61,3 +62,46 @@ def test_gpu_matches_golden(path):
     check_stats(out["stats"][0], ref, K, os.path.basename(path))
     plan.close()
     ctx.close()
+
+
+def _load_f0(path):
+    g = np.load(path, allow_pickle=False)
+    sr, n_fft, hop, idx, speechy = (int(v) for v in g["params"])
+    y = make_clip(idx, sr, float(g["seconds"]), speechy=bool(speechy))
+    return g, y, sr, n_fft, hop
+
+
+@pytest.mark.parametrize("path", GOLDEN_F0, ids=[os.path.basename(p)[:-4] for p in GOLDEN_F0])
+def test_pyin_oracle_reproduces_golden(path):
+    from oracle import pyin_ref as P
+    g, y, sr, n_fft, hop = _load_f0(path)
+    np.testing.assert_array_equal(y[:16], g["y_head"])
+    yp, _ = R.preprocess_audio(y)
+    f0, _, vp = P.pyin(yp, sr=sr, frame_length=n_fft, hop_length=hop)
+    same = np.isnan(f0) == np.isnan(g["f0"])
+    v = ~np.isnan(f0) & ~np.isnan(g["f0"])
+    same[v] &= np.abs(f0[v] - g["f0"][v]) <= 1e-9 * g["f0"][v]
+    assert same.mean() >= 0.99                       # BLAS / libm point releases may flip an ill-conditioned frame
+    np.testing.assert_allclose(vp, g["voiced_prob"], atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLDEN_F0, ids=[os.path.basename(p)[:-4] for p in GOLDEN_F0])
+def test_gpu_f0_matches_golden(path):
+    from audio_feature_extraction_amd import _native as N
+    g, y, sr, n_fft, hop = _load_f0(path)
+    ctx = N.Context(0)
+    plan = N.Plan(ctx, N.make_params(sr, n_fft, hop, 13))
+    try:
+        out = plan.f0_batch(y, np.zeros(1, np.int64), np.array([y.size], np.int64), 65.40639132514966, 2093.004522404789,
+                            want_frames=True)
+        f0 = out["f0_flat"][:g["f0"].size]
+        same = np.isnan(f0) == np.isnan(g["f0"])
+        v = ~np.isnan(f0) & ~np.isnan(g["f0"])
+        same[v] &= np.abs(f0[v] - g["f0"][v]) <= 1e-9 * g["f0"][v]
+        assert same.mean() >= 0.99
+        if same.all():
+            np.testing.assert_allclose(out["stats"][0], g["stats"], rtol=1e-10, atol=1e-12)
+    finally:
+        plan.close()
+        ctx.close()
