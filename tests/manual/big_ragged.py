@@ -1,6 +1,6 @@
 """One-off robustness run: thousands of ragged clips in one call (MFCC and f0), a sample checked against the oracle."""
 import os, sys, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from audio_feature_extraction_amd import _native as N
 from audio_feature_extraction_amd.synth import make_clip
