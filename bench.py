@@ -193,25 +193,39 @@ def main() -> None:
         for _ in range(k):
             lane["out"] = lane["plan"].extract_batch(lane["dbuf"], lane["offsets"], lane["lengths"], out=lane["out"])
 
+    # One host thread per lane for the whole run (a fresh thread pays HIP's per-thread set-up again, several
+    # milliseconds on its second call): commands go through a queue, completion through an event.
+    import queue
+    errs = []
+
+    def lane_main(lane):
+        while True:
+            cmd = lane["q"].get()
+            if cmd is None:
+                return
+            try:
+                lane_steps(lane, cmd[0], cmd[1])
+            except BaseException as e:      # a lane that dies must fail the run, not shorten it
+                errs.append(e)
+            lane["done"].set()
+
+    if S > 1:
+        for ln in lanes:
+            ln["q"], ln["done"] = queue.Queue(), threading.Event()
+            ln["thread"] = threading.Thread(target=lane_main, args=(ln,), daemon=True)
+            ln["thread"].start()
+
     def run_steps(k):
         if S == 1:
             lane_steps(lanes[0], k)
             return
         # lanes that start together stay in lockstep (their frame kernels co-run and finish together); a start
         # offset of 1/S of a lane's step keeps one lane's frame kernel over the others' small kernels
-        errs = []
-
-        def guarded(ln, k, delay):
-            try:
-                lane_steps(ln, k, delay)
-            except BaseException as e:      # a lane that dies must fail the run, not shorten it
-                errs.append(e)
-
-        th = [threading.Thread(target=guarded, args=(ln, k, i * stagger[0])) for i, ln in enumerate(lanes)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        for i, ln in enumerate(lanes):
+            ln["done"].clear()
+            ln["q"].put((k, i * stagger[0]))
+        for ln in lanes:
+            ln["done"].wait()
         if errs:
             raise errs[0]
 
@@ -223,9 +237,14 @@ def main() -> None:
 
     run_steps(1)
     t_w = time.perf_counter()
-    lane_steps(lanes[0], 3)
+    if S > 1:
+        lanes[0]["done"].clear(); lanes[0]["q"].put((3, 0.0)); lanes[0]["done"].wait()
+    else:
+        lane_steps(lanes[0], 3)
     stagger[0] = (time.perf_counter() - t_w) / 3 / S
-    run_steps(max(args.warmup, 1))
+    # at least 8 untimed passes per lane whatever --warmup says: the first few calls of a process still pay
+    # one-off costs (workspace growth, pinned staging, clock ramp) worth several steps
+    run_steps(max(args.warmup, 8))
     for ln in lanes:
         assert int((ln["out"]["status"] != 0).sum()) == 0, "synthetic clips must all succeed"
     frames_per_step = int(sum(int(ln["out"]["nframes"].sum()) for ln in lanes))
@@ -245,7 +264,10 @@ def main() -> None:
         ln["plan"].set_timing(True)
         ln["plan"].timings(reset=True)
         torch.cuda.synchronize()
-        lane_steps(ln, 5)
+        if S > 1:
+            ln["done"].clear(); ln["q"].put((5, 0.0)); ln["done"].wait()
+        else:
+            lane_steps(ln, 5)
         torch.cuda.synchronize()
         ms, cnt = ln["plan"].timings()["frames"]
         if cnt:
@@ -322,6 +344,11 @@ def main() -> None:
         }
         print(json.dumps(line), flush=True)
 
+    if S > 1:
+        for ln in lanes:
+            ln["q"].put(None)
+        for ln in lanes:
+            ln["thread"].join()
     for ln in lanes:
         ln["dbuf"].free()
         ln["plan"].close()
