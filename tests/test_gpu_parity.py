@@ -194,9 +194,10 @@ def test_linearity_of_rms_and_shift_of_mfcc(plans):
     assert np.abs(d[1:]).max() < 2e-3
 
 
-@pytest.mark.parametrize("n_mels", [40, 100, 64])
+@pytest.mark.parametrize("n_mels", [40, 100, 64, 20, 256])
 def test_other_mel_counts_on_the_tuned_kernel(ctx, n_mels):
-    """n_mels that are not a multiple of 8 leave the last filter oct partly empty (1024/256 path)."""
+    """n_mels that are not a multiple of 8 leave the last filter oct partly empty (1024/256 path); more than 128
+    filters fall back to the generic kernel."""
     from oracle import cpu_ref as R
     plan = N.Plan(ctx, N.make_params(22050, 1024, 256, 13, n_mels, "hamming", 0.97))
     try:
