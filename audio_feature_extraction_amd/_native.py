@@ -27,7 +27,7 @@ SYMBOLS = (
     "afx_version", "afx_device_count", "afx_last_error", "afx_init", "afx_destroy",
     "afx_malloc", "afx_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
     "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables",
-    "afx_extract_batch", "afx_f0_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings",
+    "afx_extract_batch", "afx_f0_batch", "afx_zcr_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings",
 )
 
 
@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
         L.afx_build_tables.argtypes = [C.POINTER(Params), vp, vp, vp]
         L.afx_extract_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
         L.afx_f0_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
+        L.afx_zcr_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp]
         L.afx_f0_build_tables.argtypes = [i32, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
         L.afx_preprocess.argtypes = [vp, vp, C.c_int64, vp, i64p, i64p, i32p]
         L.afx_plan_set_timing.argtypes = [vp, i32]
@@ -299,6 +300,25 @@ class Plan:
         if want_frames:
             out["f0_flat"], out["f0_offsets"] = f0, foffs
         return out
+
+    def zcr_batch(self, samples, offsets, lengths, flags=FLAG_PREEMPH | FLAG_TRIM, fmt=FMT_F32):
+        """Zero-crossing rate per frame (float64) of a ragged host batch: list of arrays, plus status."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        lengths = np.ascontiguousarray(lengths, np.int64)
+        n = int(offsets.shape[0])
+        want = np.int16 if fmt == FMT_S16 else np.float32
+        if not isinstance(samples, np.ndarray) or samples.dtype != want or not samples.flags.c_contiguous:
+            raise ValueError(f"samples must be a C-contiguous {want.__name__} array")
+        tmax = 1 + lengths // self.params.hop
+        zoffs = np.zeros(n, np.int64)
+        if n:
+            zoffs[1:] = np.cumsum(tmax)[:-1]
+        z = np.zeros(int(tmax.sum()) if n else 0, np.float64)
+        status = np.zeros(n, np.int32)
+        _check(lib().afx_zcr_batch(self.handle, samples.ctypes.data, int(fmt), MEM_HOST, offsets.ctypes.data,
+                                   lengths.ctypes.data, n, int(flags), z.ctypes.data, zoffs.ctypes.data,
+                                   status.ctypes.data), "afx_zcr_batch")
+        return {"zcr_flat": z, "zcr_offsets": zoffs, "status": status}
 
     def preprocess(self, y: np.ndarray):
         y = np.ascontiguousarray(y, np.float32)

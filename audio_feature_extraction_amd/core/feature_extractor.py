@@ -214,9 +214,9 @@ class AudioFeatureExtractor:
         """The per-frame matrices the reference computes and then reduces (feature_extractor.py:127-138,
         :164, :87), in the layout its experiment scripts save and its DTW aligner reads
         (04_feature_extraction_experiment/feature_extraction.py:191-215, 340-352): ``mfcc`` is
-        ``vstack([mfcc, delta, delta2])`` of shape (3*n_mfcc, T) float32, ``energy`` the RMS row (T,)
-        float32, ``f0`` the pYIN track (T,) float64 with NaN on unvoiced frames -- all of the
-        preprocessed signal, all computed on the GPU."""
+        ``vstack([mfcc, delta, delta2])`` of shape (3*n_mfcc, T) float32, ``f0`` the pYIN track (T,)
+        float64 with NaN on unvoiced frames, ``energy`` the RMS row (T,) float32, ``zcr`` the
+        zero-crossing rate (T,) float64 -- all of the preprocessed signal, all computed on the GPU."""
         y, _ = self.load_audio(audio_path)
         y = np.ascontiguousarray(y, dtype=np.float32)
         flags = _native.FLAG_PREEMPH | _native.FLAG_TRIM
@@ -228,10 +228,12 @@ class AudioFeatureExtractor:
         fr = out["frames"][0]
         T = int(out["nframes"][0])
         f0 = plan.f0_batch(y, off, ln, float(self.f0_min), float(self.f0_max), flags=flags, want_frames=True)
+        zcr = plan.zcr_batch(y, off, ln, flags=flags)
         return {
             "mfcc": np.vstack([fr["mfcc"], fr["mfcc_delta"], fr["mfcc_delta2"]]),
-            "energy": fr["rms"][0].copy(),
             "f0": f0["f0_flat"][:T].copy(),
+            "energy": fr["rms"][0].copy(),
+            "zcr": zcr["zcr_flat"][:T].copy(),
         }
 
     @staticmethod

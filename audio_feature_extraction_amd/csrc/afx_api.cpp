@@ -636,6 +636,60 @@ extern "C" int afx_f0_batch(afx_plan* pl, const void* samples, int sample_fmt, i
   return AFX_OK;
 }
 
+// ---- zero-crossing rate per frame (the sibling feature the reference's experiment scripts store) ---------
+extern "C" int afx_zcr_batch(afx_plan* pl, const void* samples, int sample_fmt, int mem_kind,
+                             const int64_t* offsets, const int64_t* lengths, int n_clips, int flags,
+                             double* out_zcr, const int64_t* zcr_offsets, int32_t* out_status) {
+  if (!pl || !offsets || !lengths || !out_zcr || !zcr_offsets || !out_status || n_clips < 0 || (!samples && n_clips > 0)) {
+    set_error("afx_zcr_batch: null/invalid argument");
+    return AFX_ERR_INVALID;
+  }
+  if (sample_fmt != AFX_FMT_F32 && sample_fmt != AFX_FMT_S16) { set_error("unknown sample format"); return AFX_ERR_INVALID; }
+  if (mem_kind != AFX_MEM_HOST && mem_kind != AFX_MEM_DEVICE) { set_error("unknown mem_kind"); return AFX_ERR_INVALID; }
+  if (n_clips == 0) return AFX_OK;
+  if (n_clips > 32768) { set_error("afx_zcr_batch: at most 32768 clips per call"); return AFX_ERR_INVALID; }
+  (void)hipGetLastError();
+  HIP_TRY(hipSetDevice(pl->device));
+  hipStream_t s = pl->ctx->stream;
+  const int n = n_clips;
+  int rc;
+  const void* d_samples = samples;
+  int64_t hi = 0, max_len = 0;
+  for (int i = 0; i < n; ++i) { hi = std::max(hi, offsets[i] + lengths[i]); max_len = std::max(max_len, lengths[i]); }
+  if (mem_kind == AFX_MEM_HOST) {
+    const size_t esz = sample_fmt == AFX_FMT_S16 ? 2 : 4;
+    if ((rc = ensure(pl->f0_in, (size_t)hi * esz + 16)) != AFX_OK) return rc;
+    if (hi > 0) HIP_TRY(hipMemcpyAsync(pl->f0_in.p, samples, (size_t)hi * esz, hipMemcpyHostToDevice, s));
+    d_samples = pl->f0_in.p;
+  }
+  if ((rc = prepare_descriptors(pl, offsets, lengths, n)) != AFX_OK) return rc;
+  size_t count = 0;
+  for (int i = 0; i < n; ++i) count = std::max<size_t>(count, (size_t)zcr_offsets[i] + (size_t)pl->h_clips[i].tmax);
+  if ((rc = ensure(pl->info, n * sizeof(ClipInfo))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->bsum, std::max<int64_t>(pl->total_tblk, 1) * 4 * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_ysig, (size_t)std::max<int64_t>(hi, 1) * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_out, std::max<size_t>(count, 1) * sizeof(double))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_offs, n * sizeof(int64_t))) != AFX_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(pl->f0_offs.p, zcr_offsets, n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(pl->f0_out.p, 0, std::max<size_t>(count, 1) * sizeof(double), s));
+  KParams kp = pl->kp;
+  kp.flags = flags; kp.fmt = sample_fmt;
+  const ClipDesc* d_clips = (const ClipDesc*)pl->clips.p;
+  ClipInfo* d_info = (ClipInfo*)pl->info.p;
+  HIP_TRY(hipMemsetAsync(d_info, 0, n * sizeof(ClipInfo), s));
+  HIP_TRY(launch_trim_blocks(s, d_samples, d_clips, d_info, (float*)pl->bsum.p, n, pl->max_tblocks, kp));
+  HIP_TRY(launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, nullptr, n, kp));
+  HIP_TRY(launch_f0_prep(s, d_samples, d_clips, d_info, (float*)pl->f0_ysig.p, n, max_len, kp));
+  HIP_TRY(launch_zcr(s, (const float*)pl->f0_ysig.p, d_clips, d_info, pl->p.n_fft, pl->p.hop, (double*)pl->f0_out.p,
+                     (const int64_t*)pl->f0_offs.p, n, pl->max_tmax));
+  std::vector<ClipInfo> h_info(n);
+  HIP_TRY(hipMemcpyAsync(out_zcr, pl->f0_out.p, count * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_info.data(), d_info, n * sizeof(ClipInfo), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i) out_status[i] = h_info[i].nonfinite ? AFX_CLIP_NONFINITE : AFX_CLIP_OK;
+  return AFX_OK;
+}
+
 extern "C" int afx_preprocess(afx_plan* pl, const float* y, int64_t n, float* out_y,
                               int64_t* start, int64_t* end, int32_t* status) {
   if (!pl || !y || !out_y || !start || !end || !status || n < 0) {

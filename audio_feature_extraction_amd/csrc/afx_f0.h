@@ -74,4 +74,7 @@ hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInf
                              uint16_t* states, double* out_stats, double* out_f0, const int64_t* f0_offsets,
                              int n_clips);
 
+hipError_t launch_zcr(hipStream_t s, const float* ysig, const ClipDesc* clips, const ClipInfo* info, int n_fft, int hop,
+                      double* out, const int64_t* out_offsets, int n_clips, int max_tmax);
+
 }  // namespace afx

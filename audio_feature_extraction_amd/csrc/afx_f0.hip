@@ -650,6 +650,46 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_zcr: librosa.feature.zero_crossing_rate of the preprocessed signal, one wave per frame.  Centre padding is
+// 'edge' (the clip's first / last sample), samples with |y| <= 1e-10 count as +0, a crossing is a change of sign
+// bit between neighbours, the first sample of a frame never is one; rate = crossings / frame_length (float64).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_zcr(const float* __restrict__ ysig, const ClipDesc* __restrict__ clips,
+                                             const ClipInfo* __restrict__ info, int n_fft, int hop,
+                                             double* __restrict__ out, const int64_t* __restrict__ out_offsets) {
+  const int clip = blockIdx.y;
+  const ClipInfo ci = info[clip];
+  if (ci.status == AFX_CLIP_NONFINITE) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= ci.T) return;
+  const ClipDesc cd = clips[clip];
+  const int64_t np = ci.end - ci.start;
+  const float* y = ysig + cd.off;
+  const int64_t g0 = (int64_t)t * hop - n_fft / 2;
+  auto neg = [&](int64_t g) -> bool {                    // sign bit of padded sample g after the 1e-10 clip
+    if (np <= 0) return false;
+    const int64_t c = g < 0 ? 0 : (g >= np ? np - 1 : g);
+    const float v = y[c];
+    return fabsf(v) <= 1e-10f ? false : (v < 0.f);       // NaN cannot occur (non-finite clips are flagged)
+  };
+  int cnt = 0;
+  for (int n = lane; n < n_fft; n += 64) {
+    if (n > 0) cnt += (neg(g0 + n) != neg(g0 + n - 1)) ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0) out[out_offsets[clip] + t] = (double)cnt / (double)n_fft;
+}
+
+hipError_t launch_zcr(hipStream_t s, const float* ysig, const ClipDesc* clips, const ClipInfo* info, int n_fft, int hop,
+                      double* out, const int64_t* out_offsets, int n_clips, int max_tmax) {
+  dim3 grid((max_tmax + 3) / 4, n_clips);
+  hipLaunchKernelGGL(k_zcr, grid, dim3(256), 0, s, ysig, clips, info, n_fft, hop, out, out_offsets);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 template <typename K>

@@ -154,6 +154,15 @@ int afx_f0_batch(afx_plan* plan,
                  double* out_f0stats, int32_t* out_status,
                  double* out_f0, const int64_t* f0_offsets);
 
+/* Zero-crossing rate per frame of the same preprocessed clips (librosa.feature.zero_crossing_rate with
+ * frame_length = n_fft, hop_length = hop, center=True): the frame-level feature the reference's experiment
+ * scripts store beside mfcc / f0 / energy (04_feature_extraction_experiment/feature_extraction.py:340-352).
+ *   out_zcr   host double buffer: clip i's T_i rates at out_zcr[zcr_offsets[i] ..]; at most 32768 clips per call */
+int afx_zcr_batch(afx_plan* plan,
+                  const void* samples, int sample_fmt, int mem_kind,
+                  const int64_t* offsets, const int64_t* lengths, int n_clips, int flags,
+                  double* out_zcr, const int64_t* zcr_offsets, int32_t* out_status);
+
 /* Host-only (no device needed): the tables afx_f0_batch uploads, for inspection and tests.
  * info[8] = min_period, max_period, n_pitch_bins, band (transition half-width), candidate
  * capacity, lags kept, lags per lane, trough slots per lane.  beta[100] = Beta(2,18) mass of

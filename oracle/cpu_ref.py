@@ -34,7 +34,7 @@ import scipy.signal
 __all__ = [
     "preemphasis", "rms", "trim", "stft", "mel_filterbank", "melspectrogram",
     "power_to_db", "mfcc", "delta", "preprocess_audio", "extract_mfcc",
-    "extract_energy", "extract_stats", "frame_count",
+    "extract_energy", "extract_stats", "frame_count", "zero_crossing_rate",
 ]
 
 
@@ -280,6 +280,22 @@ def extract_energy(y, frame_length, hop_length, return_frames: bool = False):
     if return_frames:
         out["rms"] = r
     return out
+
+
+def zero_crossing_rate(y: np.ndarray, frame_length: int = 2048, hop_length: int = 512) -> np.ndarray:
+    """librosa.feature.zero_crossing_rate(y, frame_length, hop_length, center=True) -> [T] float64
+    (the per-frame feature the reference's experiment scripts store next to mfcc / f0 / energy,
+    04_feature_extraction_experiment/feature_extraction.py:340-352).  Centre padding is ``mode='edge'``;
+    ``librosa.zero_crossings(threshold=1e-10, zero_pos=True, pad=False)``: samples with |y| <= 1e-10 count as +0,
+    a crossing is a change of ``np.signbit`` between neighbours, the first sample of a frame never is one."""
+    y = np.asarray(y)
+    yp = np.pad(y, (frame_length // 2, frame_length // 2), mode="edge")
+    fr = _frame(yp, frame_length, hop_length).copy()
+    fr[np.abs(fr) <= 1e-10] = 0
+    sign = np.signbit(fr)
+    z = np.zeros(fr.shape, dtype=bool)
+    z[1:, :] = sign[1:, :] != sign[:-1, :]
+    return np.mean(z, axis=0)
 
 
 def extract_stats(y_raw, sr=22050, frame_length=1024, hop_length=256, n_mfcc=13,

@@ -164,7 +164,8 @@ def test_frame_feature_export_matches_oracle_and_round_trips(tmp_path):
     out = str(tmp_path / "frames.npz")
     ex.save_frame_features(fr, out)
     with np.load(out) as z:
-        assert sorted(z.files) == ["energy", "f0", "mfcc"] and z["mfcc"].shape == (39, T)
+        assert sorted(z.files) == ["energy", "f0", "mfcc", "zcr"] and z["mfcc"].shape == (39, T)
+    np.testing.assert_array_equal(fr["zcr"], R.zero_crossing_rate(yp, 1024, 256))       # counts / 1024: exact
 
 
 def test_batch_process_with_several_workers_per_gpu(tmp_path):

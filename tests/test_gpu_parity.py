@@ -209,3 +209,28 @@ def test_other_mel_counts_on_the_tuned_kernel(ctx, n_mels):
         check_stats(out["stats"][0], ref, 13, f"mels{n_mels}")
     finally:
         plan.close()
+
+
+def test_zero_crossing_rate_is_exact(plans):
+    from oracle import cpu_ref as R
+    plan = plans("cfg2")
+    rng = np.random.default_rng(9)
+    clips = [make_clip(40, 22050, 1.0), make_clip(41, 22050, 1.4, speechy=True),
+             np.tile(np.array([1, -1], np.float32), 3000), (1e-11 * rng.standard_normal(4000)).astype(np.float32),
+             make_clip(42, 22050, 0.03), np.array([0.2], np.float32)]
+    lengths = np.array([c.size for c in clips], np.int64)
+    pad = (lengths + 3) // 4 * 4
+    offsets = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.int64)
+    buf = np.zeros(int(pad.sum()), np.float32)
+    for c, o in zip(clips, offsets):
+        buf[o:o + c.size] = c
+    for flags in (0, N.FLAG_PREEMPH | N.FLAG_TRIM):
+        out = plan.zcr_batch(buf, offsets, lengths, flags=flags)
+        assert (out["status"] == 0).all()
+        for i, c in enumerate(clips):
+            if flags and c.size < 2:
+                continue                                      # the oracle's pre-emphasis needs two samples
+            yp = R.preprocess_audio(c)[0] if flags else c
+            ref = R.zero_crossing_rate(yp, 1024, 256)
+            got = out["zcr_flat"][out["zcr_offsets"][i]: out["zcr_offsets"][i] + ref.size]
+            np.testing.assert_array_equal(got, ref, err_msg=f"clip {i} flags {flags}")

@@ -213,3 +213,18 @@ def test_float32_tracks_float64_truth():
     scale = np.abs(b["mfcc"]).max(axis=1, keepdims=True)
     assert (np.abs(a["mfcc"] - b["mfcc"]) / scale).max() < 2e-5
     np.testing.assert_allclose(a["rms"], b["rms"], rtol=2e-6)
+
+
+def test_zero_crossing_rate_known_answers():
+    from oracle import cpu_ref as R
+    alt = np.tile(np.array([1, -1], np.float32), 2048)
+    z = R.zero_crossing_rate(alt, 1024, 256)
+    assert z.shape == (1 + alt.size // 256,)
+    assert z[8] == 1023 / 1024                                  # interior frame: every neighbour pair but the first slot
+    assert z[0] == 511 / 1024                                   # first frame: 512 edge-padded samples, then the signal
+    assert (R.zero_crossing_rate(np.ones(3000, np.float32), 1024, 256) == 0).all()
+    tiny = np.tile(np.array([1e-11, -1e-11], np.float32), 1000)  # |y| <= 1e-10 counts as +0
+    assert (R.zero_crossing_rate(tiny, 1024, 256) == 0).all()
+    half = np.concatenate([np.ones(2048, np.float32), -np.ones(2048, np.float32)])
+    z = R.zero_crossing_rate(half, 1024, 256)
+    assert z.max() == 1 / 1024 and (z > 0).sum() == 3            # 4 frames span the crossing; in one it is slot 0, which never counts
