@@ -41,12 +41,16 @@ struct F0Tables {
   const double* bfact;    // [cap + 1] (1 - e^-2) / (1 - e^-2n)  (scipy.stats.boltzmann.pmf normaliser)
   const double* bexp;     // [cap + 1] e^-2k
   const double* lt;       // [2][2 * band + 1][2 * band + 1] log(switch * local[row class][d] + tiny)
+  const double* ltw;      // [2 * band + 1][2] the interior row as the band walk meets it: {stay, switch} of entry 2 band - e
   const double* freqs;    // [n_bins] fmin * 2^(b / 120)
 };
 
+// (maximum, first arg-max) of one Viterbi value column: the best out-of-band source of the next step
+struct VitBest { double value; int32_t arg; int32_t pad; };
+
 struct HostF0Tables {
   F0Params p{};
-  std::vector<double> thr, beta, cumbeta, bfact, bexp, lt, freqs;
+  std::vector<double> thr, beta, cumbeta, bfact, bexp, lt, ltw, freqs;
 };
 
 // builds every table from (sr, n_fft, hop, fmin, fmax); returns false when the combination is unsupported
@@ -59,6 +63,8 @@ size_t f0_viterbi_lds_bytes(const F0Params& fp);
 // per-frame candidate record sizes (device workspace)
 inline size_t f0_cand_bins_bytes(const F0Params& fp, int64_t frames) { return (size_t)frames * fp.cap * sizeof(int16_t); }
 inline size_t f0_cand_prob_bytes(const F0Params& fp, int64_t frames) { return (size_t)frames * fp.cap * sizeof(double); }
+// Viterbi value columns kept for back-tracking: 2 n_bins doubles per frame
+inline size_t f0_vrows_bytes(const F0Params& fp, int64_t frames) { return (size_t)frames * 2 * fp.n_bins * sizeof(double); }
 
 hipError_t launch_f0_prep(hipStream_t s, const void* samples, const ClipDesc* clips, const ClipInfo* info,
                           float* ysig, int n_clips, int64_t max_len, const KParams& kp);
@@ -70,7 +76,7 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
                          int n_clips, int max_tmax);
 hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const F0Tables& tb,
                              const F0Params& fp, const int32_t* cand_cnt, const double* cand_vp,
-                             const int16_t* cand_bin, const double* cand_prob, uint16_t* ptr_rows,
+                             const int16_t* cand_bin, const double* cand_prob, double* vrows, VitBest* vbest,
                              uint16_t* states, double* out_stats, double* out_f0, const int64_t* f0_offsets,
                              int n_clips);
 

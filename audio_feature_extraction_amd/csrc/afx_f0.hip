@@ -416,12 +416,25 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
 // normalised, so log(A + tiny) has 2 x (2 band + 1) distinct rows of (2 band + 1) entries -- held in
 // LDS -- and log(tiny) everywhere else.  Out-of-band moves therefore all cost the same: the best of them
 // is the previous column's global maximum, which is computed once per step.
+//
+// Back-pointers are not formed in the forward pass.  Back-tracking visits one state per step, so only T of
+// the T x 2 n_bins arg-maxima are ever used: the forward pass keeps the *values* (add + max per band entry,
+// half the instructions of a running arg-max and no index registers, which is what lets two workgroups
+// share a CU) and writes every value column to HBM (2 n_bins doubles per frame); the backward pass then
+// recomputes, for the one state on the path, the same sums in the same order and takes their first maximum
+// (numpy's argmax rule) -- bit-identical to forming all pointers up front.
 // ---------------------------------------------------------------------------------------------
 constexpr int kVitThreads = 640;
-constexpr int kVitRows = 4;           // back-pointer rows buffered in LDS during the forward pass
-constexpr int kVitBackRows = 16;      // rows per LDS refill while back-tracking (reuses the forward pass's arrays)
 
-struct VitLds { size_t v, olp, lt, red, pb, total; };
+typedef const double __attribute__((address_space(4))) cdouble_k;   // constant address space: uniform reads become s_load
+__device__ __forceinline__ cdouble_k* as_constant(const double* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (cdouble_k*)p;
+#pragma clang diagnostic pop
+}
+
+struct VitLds { size_t v, olp, lt, red, total; };
 __host__ __device__ inline VitLds vit_lds(const F0Params& fp) {
   const size_t S = 2 * (size_t)fp.n_bins, width = 2 * (size_t)fp.band + 1;
   VitLds L;
@@ -429,35 +442,36 @@ __host__ __device__ inline VitLds vit_lds(const F0Params& fp) {
   L.olp = 2 * S;                             // n_bins doubles
   L.lt = L.olp + fp.n_bins;                  // 2 * width * width doubles
   L.red = L.lt + 2 * width * width;          // 32 doubles + 32 ints (16 doubles)
-  L.pb = L.red + 48;                         // kVitRows * S uint16
-  L.total = L.pb * sizeof(double) + kVitRows * S * sizeof(uint16_t) + 16;
+  L.total = (L.red + 48) * sizeof(double);
   return L;
 }
 size_t f0_viterbi_lds_bytes(const F0Params& fp) { return vit_lds(fp).total; }
 
-__global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __restrict__ clips,
-                                                            const ClipInfo* __restrict__ info,
-                                                            F0Tables tb, F0Params fp,
-                                                            const int32_t* __restrict__ cand_cnt,
-                                                            const double* __restrict__ cand_vp,
-                                                            const int16_t* __restrict__ cand_bin,
-                                                            const double* __restrict__ cand_prob,
-                                                            uint16_t* __restrict__ ptr_rows,
-                                                            uint16_t* __restrict__ states,
-                                                            double* __restrict__ out_stats,
-                                                            double* __restrict__ out_f0,
-                                                            const int64_t* __restrict__ f0_offsets) {
+__global__ __launch_bounds__(kVitThreads, 2) void k_f0_viterbi(const ClipDesc* __restrict__ clips,
+                                                               const ClipInfo* __restrict__ info,
+                                                               F0Tables tb, F0Params fp,
+                                                               const int32_t* __restrict__ cand_cnt,
+                                                               const double* __restrict__ cand_vp,
+                                                               const int16_t* __restrict__ cand_bin,
+                                                               const double* __restrict__ cand_prob,
+                                                               double* __restrict__ vrows,
+                                                               VitBest* __restrict__ vbest,
+                                                               uint16_t* __restrict__ states,
+                                                               double* __restrict__ out_stats,
+                                                               double* __restrict__ out_f0,
+                                                               const int64_t* __restrict__ f0_offsets) {
   extern __shared__ double smv[];
   const int clip = blockIdx.x;
   const ClipInfo ci = info[clip];
   double* st = out_stats + (size_t)clip * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = kVitThreads / 64;
+  const ClipDesc cd = clips[clip];
   if (ci.status == AFX_CLIP_NONFINITE || ci.T < 1) {
     if (tid == 0) { st[0] = 0.0; st[1] = 0.0; st[2] = 1.0; st[3] = 0.0; }
+    if (out_f0) for (int t = tid; t < cd.tmax; t += kVitThreads) out_f0[f0_offsets[clip] + t] = (double)NAN;
     return;
   }
-  const ClipDesc cd = clips[clip];
   const int T = ci.T, nb = fp.n_bins, S = 2 * nb, band = fp.band, width = 2 * band + 1;
   const VitLds L = vit_lds(fp);
   double* vprev = smv + L.v;
@@ -466,8 +480,9 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
   double* LT = smv + L.lt;
   double* redv = smv + L.red;
   int* redi = reinterpret_cast<int*>(redv + 32);
-  uint16_t* PB = reinterpret_cast<uint16_t*>(smv + L.pb);
   const double c0 = fp.c0;
+  double* const vclip = vrows + (size_t)cd.frame_base * S;      // this clip's value columns, row t at t * S
+  VitBest* const bclip = vbest + cd.frame_base;                 // (max, first argmax) of column t - 1 at [t]
 
   for (int i = tid; i < 2 * width * width; i += kVitThreads) LT[i] = tb.lt[i];
   const double lpi_u = log(1.0 / (double)nb + fp.tiny);
@@ -492,8 +507,11 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
   };
 
   // candidate list of the step after the current one rides in registers (one entry per thread; cap <= threads)
-  const double* LTs = LT;                               // stay, interior row class
-  const double* LTw = LT + (size_t)width * width;       // switch, interior row class
+  const double* LTs = LT;                               // stay
+  const double* LTw = LT + (size_t)width * width;       // switch
+  // the interior row class (every source at least `band` bins from both range ends) is read through the scalar
+  // cache: its index is wave-uniform, so the band walk's weights cost no LDS traffic and no vector registers
+  cdouble_k* const kk = as_constant(tb.ltw);           // {stay, switch} per band entry, in walk order
   int pf_cnt = cand_cnt[cd.frame_base];
   double pf_vp = cand_vp[cd.frame_base];
   int pf_bin = -1; double pf_prob = 0.0;
@@ -512,22 +530,20 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
       if (tid < pf_cnt) { pf_bin = cand_bin[ns * fp.cap + tid]; pf_prob = cand_prob[ns * fp.cap + tid]; }
     }
     __syncthreads();
+    double* const vout = vclip + (size_t)t * S;
     if (t == 0) {
-      for (int j = tid; j < S; j += kVitThreads) vcur[j] = j < nb ? olp[j] + c0 : lu + lpi_u;
+      for (int j = tid; j < S; j += kVitThreads) { const double x = j < nb ? olp[j] + c0 : lu + lpi_u; vcur[j] = x; vout[j] = x; }
     } else {
       double gmax = 0.0; int garg = 0;
       if (!(fp.debug & 2)) block_argmax(vprev, gmax, garg);
+      if (tid == 0) { VitBest vb; vb.value = gmax; vb.arg = garg; vb.pad = 0; bclip[t] = vb; }
       const int gb = garg >= nb ? garg - nb : garg;
       const double* v0 = vprev;                          // voiced sources
       const double* v1 = vprev + nb;                     // unvoiced sources
-      // one thread per pitch bin jb: both targets (voiced jb, unvoiced jb) from one walk over the band.
-      // x_yz: best value / source bin for source voicing y -> target voicing z; sources in ascending index,
-      // strict '>' keeps the first maximum (numpy argmax).
+      // one thread per pitch bin jb: both targets (voiced jb, unvoiced jb) from one walk over the band
       for (int jb = tid; jb < nb; jb += kVitThreads) {
         const int blo = jb - band < 0 ? 0 : jb - band, bhi = jb + band > nb - 1 ? nb - 1 : jb + band;
-        double m00 = -INFINITY, m01 = -INFINITY, m10 = -INFINITY, m11 = -INFINITY;
-        int i00 = 0, i01 = 0, i10 = 0, i11 = 0;
-        auto upd = [](double c, int b, double& m, int& i) { const bool g = c > m; m = fmax(m, c); i = g ? b : i; };
+        double bv = -INFINITY, bu = -INFINITY;           // best move into (voiced jb), (unvoiced jb)
         // log-transition entry of source b -> target jb is LT[rc(b)][jb - b + band]; rc = 0 for interior sources,
         // 1 + b below `band`, 1 + band + (nb - 1 - b) within `band` of the top: three runs of b, each with a
         // constant table stride
@@ -538,8 +554,8 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
             const double a0 = v0[b], a1 = v1[b];
             const double ws = *ps, ww = *pw;
             ps += stride; pw += stride;
-            upd(a0 + ws, b, m00, i00); upd(a0 + ww, b, m01, i01);
-            upd(a1 + ww, b, m10, i10); upd(a1 + ws, b, m11, i11);
+            bv = fmax(bv, fmax(a0 + ws, a1 + ww));
+            bu = fmax(bu, fmax(a0 + ww, a1 + ws));
           }
         };
         if (fp.debug & 1) {
@@ -547,13 +563,12 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
         } else if (jb >= 2 * band && jb <= nb - 1 - 2 * band) {  // every source row is an interior row
           const double* p0 = v0 + (jb - band);
           const double* p1 = v1 + (jb - band);
-#pragma unroll 3
+#pragma unroll 4
           for (int e = 0; e < width; ++e) {
             const double a0 = p0[e], a1 = p1[e];
-            const double ws = LTs[2 * band - e], ww = LTw[2 * band - e];
-            const int b = jb - band + e;
-            upd(a0 + ws, b, m00, i00); upd(a0 + ww, b, m01, i01);
-            upd(a1 + ww, b, m10, i10); upd(a1 + ws, b, m11, i11);
+            const double ws = kk[2 * e], ww = kk[2 * e + 1];
+            bv = fmax(bv, fmax(a0 + ws, a1 + ww));
+            bu = fmax(bu, fmax(a0 + ww, a1 + ws));
           }
         } else {
           const int lo_end = bhi < band - 1 ? bhi : band - 1;                    // sources with rc = 1 + b
@@ -563,52 +578,58 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
           const int hi0 = blo > nb - band ? blo : nb - band;                     // sources with rc = 1 + band + (nb - 1 - b)
           if (hi0 <= bhi) scan(hi0, bhi, (1 + band + (nb - 1 - hi0)) * width + (jb - hi0 + band), -(width + 1));
         }
-        // target voiced: voiced sources first (lower index), then unvoiced; target unvoiced likewise
-        double bv = m00; int kv = i00;
-        if (m10 > bv) { bv = m10; kv = nb + i10; }
-        double bu = m01; int ku = i01;
-        if (m11 > bu) { bu = m11; ku = nb + i11; }
         if (gb < blo || gb > bhi) {                      // the best out-of-band source
           const double cand = gmax + c0;
-          if (cand > bv || (cand == bv && garg < kv)) { bv = cand; kv = garg; }
-          if (cand > bu || (cand == bu && garg < ku)) { bu = cand; ku = garg; }
+          bv = fmax(bv, cand); bu = fmax(bu, cand);
         }
-        vcur[jb] = olp[jb] + bv;
-        vcur[nb + jb] = lu + bu;
-        PB[(t % kVitRows) * S + jb] = (uint16_t)kv;
-        PB[(t % kVitRows) * S + nb + jb] = (uint16_t)ku;
+        const double xv = olp[jb] + bv, xu = lu + bu;
+        vcur[jb] = xv; vcur[nb + jb] = xu;
+        vout[jb] = xv; vout[nb + jb] = xu;
       }
-    }
-    __syncthreads();
-    if (t > 0 && ((t % kVitRows) == kVitRows - 1 || t == T - 1)) {
-      const int r0 = t - (t % kVitRows);
-      const int nrows = t - r0 + 1;
-      uint16_t* dst = ptr_rows + (cd.frame_base + r0) * (int64_t)S;
-      for (int i = tid; i < nrows * S; i += kVitThreads) dst[i] = PB[i];
     }
     double* tmp = vprev; vprev = vcur; vcur = tmp;
     __syncthreads();
   }
-  // ---- last state, back-tracking through the stored rows (a block of rows at a time through LDS)
+  // ---- last state, then back-tracking: the arg-max of the one state on the path, a step at a time
   double gmax; int garg;
   block_argmax(vprev, gmax, garg);
   uint16_t* sts = states + cd.frame_base;
-  int cur = garg;
-  if (tid == 0) sts[T - 1] = (uint16_t)cur;
-  uint16_t* BB = reinterpret_cast<uint16_t*>(smv);       // value / observation / transition arrays are dead now
-  for (int r0 = ((T - 1) / kVitBackRows) * kVitBackRows; r0 >= 0; r0 -= kVitBackRows) {
-    const int r1 = r0 + kVitBackRows - 1 < T - 1 ? r0 + kVitBackRows - 1 : T - 1;   // row t maps the state at t to t-1
-    const int nrows = r1 - r0 + 1;
-    const uint16_t* src = ptr_rows + (cd.frame_base + r0) * (int64_t)S;
-    for (int i = tid; i < nrows * S; i += kVitThreads) BB[i] = src[i];
-    __syncthreads();
-    if (tid == 0) {
-      for (int t = r1; t >= r0 && t >= 1; --t) {
-        cur = BB[(t - r0) * S + cur];
-        sts[t - 1] = (uint16_t)cur;
+  __threadfence();
+  __syncthreads();
+  if (wave == 0) {
+    int cur = garg;
+    if (lane == 0) sts[T - 1] = (uint16_t)cur;
+    for (int t = T - 1; t >= 1; --t) {
+      const double* R = vclip + (size_t)(t - 1) * S;     // column t - 1
+      const VitBest gbst = bclip[t];                     // its maximum: the best out-of-band source
+      const bool tv = cur < nb;                          // target voiced?
+      const int jb = tv ? cur : cur - nb;
+      const int b = jb - band + lane;                    // this lane's source bin
+      const bool ok = lane < width && b >= 0 && b < nb;
+      double best = -INFINITY; int bi = 1 << 30;
+      if (ok) {
+        const int rc = b < band ? 1 + b : (b > nb - 1 - band ? 1 + band + (nb - 1 - b) : 0);
+        const int idx = rc * width + (2 * band - lane);  // entry jb - b + band of that row
+        const double ws = LTs[idx], ww = LTw[idx];
+        const double a0 = R[b], a1 = R[nb + b];
+        const double cv = a0 + (tv ? ws : ww), cu = a1 + (tv ? ww : ws);
+        best = cv; bi = b;                               // voiced sources come first (lower index)
+        if (cu > best) { best = cu; bi = nb + b; }
       }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        const double ov = shfl_xor_d(best, o); const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      const int blo = jb - band < 0 ? 0 : jb - band, bhi = jb + band > nb - 1 ? nb - 1 : jb + band;
+      const int gb = gbst.arg >= nb ? gbst.arg - nb : gbst.arg;
+      if (gb < blo || gb > bhi) {
+        const double cand = gbst.value + c0;
+        if (cand > best || (cand == best && gbst.arg < bi)) { best = cand; bi = gbst.arg; }
+      }
+      cur = __builtin_amdgcn_readfirstlane(bi);
+      if (lane == 0) sts[t - 1] = (uint16_t)cur;
     }
-    __syncthreads();
   }
   __threadfence_block();
   __syncthreads();
@@ -630,6 +651,7 @@ __global__ __launch_bounds__(kVitThreads) void k_f0_viterbi(const ClipDesc* __re
     if (voiced) { s1 += f; c1 += 1.0; }
     if (out_f0) out_f0[f0_offsets[clip] + t] = voiced ? f : (double)NAN;
   }
+  if (out_f0) for (int t = T + tid; t < cd.tmax; t += kVitThreads) out_f0[f0_offsets[clip] + t] = (double)NAN;   // trimmed away
   const double cntv = block_sum(c1);
   const double sum = block_sum(s1);
   if (cntv > 0.0) {
@@ -733,14 +755,14 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
 
 hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const F0Tables& tb,
                              const F0Params& fp, const int32_t* cand_cnt, const double* cand_vp,
-                             const int16_t* cand_bin, const double* cand_prob, uint16_t* ptr_rows,
+                             const int16_t* cand_bin, const double* cand_prob, double* vrows, VitBest* vbest,
                              uint16_t* states, double* out_stats, double* out_f0, const int64_t* f0_offsets,
                              int n_clips) {
   const size_t lds = f0_viterbi_lds_bytes(fp);
   hipError_t e = allow_lds(k_f0_viterbi, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_f0_viterbi, dim3(n_clips), dim3(kVitThreads), lds, s, clips, info, tb, fp, cand_cnt,
-                     cand_vp, cand_bin, cand_prob, ptr_rows, states, out_stats, out_f0, f0_offsets);
+                     cand_vp, cand_bin, cand_prob, vrows, vbest, states, out_stats, out_f0, f0_offsets);
   return hipGetLastError();
 }
 

@@ -88,6 +88,9 @@ bool build_f0_tables(int sr, int n_fft, int hop, double fmin, double fmax, HostF
       for (int d = dlo; d <= dhi; ++d)
         t.lt[((size_t)v * NC + rc) * width + d] = std::log(sw[v] * (win[d] / rowsum) + p.tiny);
   }
+  t.ltw.resize((size_t)2 * width);
+  for (int e = 0; e < width; ++e)
+    for (int v = 0; v < 2; ++v) t.ltw[2 * e + v] = t.lt[(size_t)v * NC * width + (2 * p.band - e)];
   t.freqs.resize(p.n_bins);
   for (int b = 0; b < p.n_bins; ++b) t.freqs[b] = fmin * std::pow(2.0, (double)b / p.bins_per_octave);
   return true;
