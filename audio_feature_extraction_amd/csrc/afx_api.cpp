@@ -50,7 +50,7 @@ struct afx_plan {
   HostF0Tables f0_ht;
   F0Tables f0_dt{};
   std::vector<void*> f0_allocs;
-  DevBuf f0_in, f0_ysig, f0_energy, f0_cnt, f0_vp, f0_bin, f0_prob, f0_ptr, f0_best, f0_states, f0_stats, f0_out, f0_offs;
+  DevBuf f0_in, f0_ysig, f0_energy, f0_cnt, f0_vp, f0_bin, f0_prob, f0_lprob, f0_lu, f0_ptr, f0_best, f0_states, f0_stats, f0_out, f0_offs;
   // cached per-batch descriptors
   std::vector<int64_t> c_off, c_len;
   std::vector<ClipDesc> h_clips;
@@ -244,7 +244,7 @@ extern "C" void afx_plan_destroy(afx_plan* pl) {
   for (void* d : pl->table_allocs) (void)hipFree(d);
   for (void* q : pl->f0_allocs) (void)hipFree(q);
   release(pl->f0_in); release(pl->f0_ysig); release(pl->f0_energy); release(pl->f0_cnt); release(pl->f0_vp);
-  release(pl->f0_bin); release(pl->f0_prob); release(pl->f0_ptr); release(pl->f0_best); release(pl->f0_states); release(pl->f0_stats);
+  release(pl->f0_bin); release(pl->f0_prob); release(pl->f0_ptr); release(pl->f0_best); release(pl->f0_lprob); release(pl->f0_lu); release(pl->f0_states); release(pl->f0_stats);
   release(pl->f0_out); release(pl->f0_offs);
   release(pl->samples); release(pl->clips); release(pl->info); release(pl->blocks); release(pl->bsum);
   release(pl->logmel); release(pl->rms); release(pl->mfcc); release(pl->stats); release(pl->frames);
@@ -541,6 +541,8 @@ static int f0_chunk(afx_plan* pl, const void* d_samples, int fmt, const int64_t*
   if ((rc = ensure(pl->f0_prob, f0_cand_prob_bytes(fp, frames))) != AFX_OK) return rc;
   if ((rc = ensure(pl->f0_ptr, f0_vrows_bytes(fp, frames))) != AFX_OK) return rc;
   if ((rc = ensure(pl->f0_best, (size_t)frames * sizeof(VitBest))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_lprob, f0_cand_prob_bytes(fp, frames))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->f0_lu, (size_t)frames * sizeof(double))) != AFX_OK) return rc;
   if ((rc = ensure(pl->f0_states, (size_t)frames * sizeof(uint16_t))) != AFX_OK) return rc;
   if ((rc = ensure(pl->f0_stats, (size_t)n * 4 * sizeof(double))) != AFX_OK) return rc;
   double* d_f0 = nullptr;
@@ -566,7 +568,8 @@ static int f0_chunk(afx_plan* pl, const void* d_samples, int fmt, const int64_t*
                         (int32_t*)pl->f0_cnt.p, (double*)pl->f0_vp.p, (int16_t*)pl->f0_bin.p, (double*)pl->f0_prob.p,
                         n, pl->max_tmax));
   HIP_TRY(launch_f0_viterbi(s, d_clips, d_info, pl->f0_dt, fp, (const int32_t*)pl->f0_cnt.p, (const double*)pl->f0_vp.p,
-                            (const int16_t*)pl->f0_bin.p, (const double*)pl->f0_prob.p, (double*)pl->f0_ptr.p, (VitBest*)pl->f0_best.p,
+                            (const int16_t*)pl->f0_bin.p, (const double*)pl->f0_prob.p, (double*)pl->f0_lprob.p,
+                            (double*)pl->f0_lu.p, frames, (double*)pl->f0_ptr.p, (VitBest*)pl->f0_best.p,
                             (uint16_t*)pl->f0_states.p, (double*)pl->f0_stats.p, d_f0, (const int64_t*)pl->f0_offs.p, n));
   std::vector<ClipInfo> h_info(n);
   HIP_TRY(hipMemcpyAsync(out_stats, pl->f0_stats.p, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -616,8 +619,8 @@ extern "C" int afx_f0_batch(afx_plan* pl, const void* samples, int sample_fmt, i
     if (hi > 0) HIP_TRY(hipMemcpyAsync(pl->f0_in.p, samples, (size_t)hi * esz, hipMemcpyHostToDevice, pl->ctx->stream));
     d_samples = pl->f0_in.p;
   }
-  // the stage keeps ~13 KB of workspace per frame (Viterbi value columns 9.6 KB, candidates, energies): bound it
-  // per chunk (17 GB; a chunk should still hold several clips per CU so that every CU runs two Viterbi workgroups)
+  // the stage keeps ~14 KB of workspace per frame (Viterbi value columns 9.6 KB, candidates and their logs, energies): bound it
+  // per chunk (18 GB; a chunk should still hold several clips per CU so that every CU runs two Viterbi workgroups)
   const int64_t kMaxFrames = 1280 * 1024;
   int c0 = 0;
   while (c0 < n_clips) {

@@ -426,6 +426,28 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
 // ---------------------------------------------------------------------------------------------
 constexpr int kVitThreads = 640;
 
+#define F0_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, false)
+template <int CTRL> __device__ __forceinline__ double dpp_dd(double v) {
+  return __hiloint2double(F0_DPP_I(__double2hiint(v), CTRL), F0_DPP_I(__double2loint(v), CTRL));
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {         // uniform result
+  v = fmax(v, dpp_dd<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = fmax(v, dpp_dd<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = fmax(v, dpp_dd<0x141>(v));     // row_half_mirror
+  v = fmax(v, dpp_dd<0x140>(v));     // row_mirror
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  auto rl = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l)); };
+  return fmax(fmax(rl(0), rl(16)), fmax(rl(32), rl(48)));
+}
+__device__ __forceinline__ int wave_min_dpp(int v) {               // uniform result
+  v = min(v, F0_DPP_I(v, 0xB1));
+  v = min(v, F0_DPP_I(v, 0x4E));
+  v = min(v, F0_DPP_I(v, 0x141));
+  v = min(v, F0_DPP_I(v, 0x140));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 typedef const double __attribute__((address_space(4))) cdouble_k;   // constant address space: uniform reads become s_load
 __device__ __forceinline__ cdouble_k* as_constant(const double* p) {
 #pragma clang diagnostic push
@@ -438,22 +460,38 @@ struct VitLds { size_t v, olp, lt, red, total; };
 __host__ __device__ inline VitLds vit_lds(const F0Params& fp) {
   const size_t S = 2 * (size_t)fp.n_bins, width = 2 * (size_t)fp.band + 1;
   VitLds L;
-  L.v = 0;                                   // vA, vB: 2 S doubles
-  L.olp = 2 * S;                             // n_bins doubles
-  L.lt = L.olp + fp.n_bins;                  // 2 * width * width doubles
-  L.red = L.lt + 2 * width * width;          // 32 doubles + 32 ints (16 doubles)
+  L.v = 0;                                   // two value columns of 2 (n_bins + 2 band) + 4 band doubles
+  L.olp = 2 * (S + 8 * fp.band);             // 3 n_bins doubles
+  L.lt = L.olp + 3 * fp.n_bins;              // 2 * width * width doubles
+  L.red = L.lt + 2 * width * width;          // 32 doubles + 32 ints (16 doubles): two sets of per-wave partials
   L.total = (L.red + 48) * sizeof(double);
   return L;
 }
 size_t f0_viterbi_lds_bytes(const F0Params& fp) { return vit_lds(fp).total; }
 
-__global__ __launch_bounds__(kVitThreads, 2) void k_f0_viterbi(const ClipDesc* __restrict__ clips,
+// k_f0_logs: the log observation values the Viterbi pass scatters -- log(p + tiny) per candidate and the unvoiced
+// bins' common log((1 - voiced_prob) / n_bins + tiny) -- one wave per frame slot.  Kept out of the Viterbi step
+// loop, where a wave's instruction count is the critical path.
+__global__ __launch_bounds__(256) void k_f0_logs(const int32_t* __restrict__ cand_cnt, const double* __restrict__ cand_vp,
+                                                 const double* __restrict__ cand_prob, double* __restrict__ cand_lp,
+                                                 double* __restrict__ cand_lu, int64_t frames, F0Params fp) {
+  const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (f >= frames) return;
+  int cnt = cand_cnt[f];                                 // slots between clips hold nothing: any value is harmless
+  cnt = cnt < 0 ? 0 : (cnt > fp.cap ? fp.cap : cnt);
+  for (int i = lane; i < cnt; i += 64) cand_lp[f * fp.cap + i] = log(cand_prob[f * fp.cap + i] + fp.tiny);
+  if (lane == 0) cand_lu[f] = log((1.0 - cand_vp[f]) / (double)fp.n_bins + fp.tiny);
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* __restrict__ clips,
                                                                const ClipInfo* __restrict__ info,
                                                                F0Tables tb, F0Params fp,
                                                                const int32_t* __restrict__ cand_cnt,
-                                                               const double* __restrict__ cand_vp,
                                                                const int16_t* __restrict__ cand_bin,
-                                                               const double* __restrict__ cand_prob,
+                                                               const double* __restrict__ cand_lp,
+                                                               const double* __restrict__ cand_lu,
                                                                double* __restrict__ vrows,
                                                                VitBest* __restrict__ vbest,
                                                                uint16_t* __restrict__ states,
@@ -464,6 +502,18 @@ __global__ __launch_bounds__(kVitThreads, 2) void k_f0_viterbi(const ClipDesc* _
   const int clip = blockIdx.x;
   const ClipInfo ci = info[clip];
   double* st = out_stats + (size_t)clip * 4;
+  // AFX_F0_DEBUG & 8: per-phase cycle counts of workgroup 0, printed per wave (developer aid)
+  unsigned long long ph[8] = {}, ph_t = 0;
+  auto stamp = [&](int i) {
+    if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i >= 0) ph[i] += now - ph_t;
+      ph_t = now;
+    }
+  };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = kVitThreads / 64;
   const ClipDesc cd = clips[clip];
@@ -474,9 +524,12 @@ __global__ __launch_bounds__(kVitThreads, 2) void k_f0_viterbi(const ClipDesc* _
   }
   const int T = ci.T, nb = fp.n_bins, S = 2 * nb, band = fp.band, width = 2 * band + 1;
   const VitLds L = vit_lds(fp);
-  double* vprev = smv + L.v;
-  double* vcur = vprev + S;
-  double* olp = smv + L.olp;
+  const int VM = nb + 2 * band;                                 // main cells per voicing (guards included)
+  const int VS = 2 * VM + 4 * band;                             // doubles per value column: main[2], edge[2]
+  double* const vbuf = smv + L.v;
+  double* vprev = vbuf;
+  double* vcur = vbuf + VS;
+  double* olp3 = smv + L.olp;                                   // three observation columns in rotation
   double* LT = smv + L.lt;
   double* redv = smv + L.red;
   int* redi = reinterpret_cast<int*>(redv + 32);
@@ -485,84 +538,118 @@ __global__ __launch_bounds__(kVitThreads, 2) void k_f0_viterbi(const ClipDesc* _
   VitBest* const bclip = vbest + cd.frame_base;                 // (max, first argmax) of column t - 1 at [t]
 
   for (int i = tid; i < 2 * width * width; i += kVitThreads) LT[i] = tb.lt[i];
+  for (int i = tid; i < 3 * nb; i += kVitThreads) olp3[i] = c0;
+  for (int i = tid; i < 2 * VS; i += kVitThreads) vbuf[i] = -INFINITY;      // guards and edge-class cells stay -inf
   const double lpi_u = log(1.0 / (double)nb + fp.tiny);
 
-  // block-wide (max value, lowest index) of v[0..S)
-  auto block_argmax = [&](const double* v, double& gmax, int& garg) {
+  // (max value, lowest index) over the wave of a per-lane (value, index): DPP butterflies, no LDS round trips
+  auto wave_best = [&](double& bv, int& bi) {
+    const double m = wave_max_dpp(bv);
+    bi = wave_min_dpp(bv == m ? bi : (1 << 30));
+    bv = m;
+  };
+  // The block-wide (max, first arg-max) of a column is assembled from per-wave partials that the producing step
+  // leaves in LDS (two sets, alternating), so that a step needs a single barrier.
+  auto put_partial = [&](int set, double bv, int bi) {
+    wave_best(bv, bi);
+    if (lane == 0) { redv[set * 16 + wave] = bv; redi[set * 16 + wave] = bi; }
+  };
+  auto get_best = [&](int set, double& gmax, int& garg) {
     double bv = -INFINITY; int bi = 1 << 30;
-    for (int j = tid; j < S; j += kVitThreads) { const double x = v[j]; if (x > bv) { bv = x; bi = j; } }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      const double ov = shfl_xor_d(bv, o); const int oi = __shfl_xor(bi, o);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
-    __syncthreads();
-    gmax = redv[0]; garg = redi[0];
-    for (int w = 1; w < NW; ++w) {
-      const double ov = redv[w]; const int oi = redi[w];
-      if (ov > gmax || (ov == gmax && oi < garg)) { gmax = ov; garg = oi; }
-    }
-    __syncthreads();
+    if (lane < NW) { bv = redv[set * 16 + lane]; bi = redi[set * 16 + lane]; }
+    wave_best(bv, bi);
+    gmax = bv; garg = bi;
   };
 
-  // candidate list of the step after the current one rides in registers (one entry per thread; cap <= threads)
   const double* LTs = LT;                               // stay
   const double* LTw = LT + (size_t)width * width;       // switch
   // the interior row class (every source at least `band` bins from both range ends) is read through the scalar
   // cache: its index is wave-uniform, so the band walk's weights cost no LDS traffic and no vector registers
   cdouble_k* const kk = as_constant(tb.ltw);           // {stay, switch} per band entry, in walk order
-  int pf_cnt = cand_cnt[cd.frame_base];
-  double pf_vp = cand_vp[cd.frame_base];
-  int pf_bin = -1; double pf_prob = 0.0;
-  if (tid < pf_cnt) { pf_bin = cand_bin[cd.frame_base * fp.cap + tid]; pf_prob = cand_prob[cd.frame_base * fp.cap + tid]; }
 
+  // Value columns in LDS, two in rotation.  A column is kept as
+  //   main[v][band + b]  b = -band .. nb - 1 + band: the value of (voicing v, bin b) when b is an interior-class
+  //                      source, -inf in the guard cells and for the edge-class sources (b < band, b >= nb - band),
+  //   edge[v][k]         the true values of the 2 band edge-class sources (low ones first),
+  // so that *every* target walks its band with the interior row's weights and no masking (a missing source reads
+  // -inf), and only the two waves that own targets within 2 band of a range end add the edge-class sources, one
+  // uniform table row per source.
+  auto put_value = [&](double* col, int jb, double xv, double xu) {
+    if (jb < band) { col[2 * VM + jb] = xv; col[2 * VM + 2 * band + jb] = xu; }
+    else if (jb >= nb - band) { const int k = band + jb - (nb - band); col[2 * VM + k] = xv; col[2 * VM + 2 * band + k] = xu; }
+    else { col[band + jb] = xv; col[VM + band + jb] = xu; }
+  };
+
+  // Observation columns: three LDS columns in rotation, all log(0) except where a step's candidates were
+  // scattered.  During step t a thread scatters its candidate of step t + 1 (loaded a step earlier) and takes
+  // back the one it scattered for step t - 1; the three touch different columns, so the step's one barrier
+  // orders everything.  The logs come from k_f0_logs.
+  auto load_cand = [&](int t, int& bin, double& lp, double& lu_) {
+    const int64_t ns = cd.frame_base + t;
+    const int cnt = cand_cnt[ns];
+    lu_ = cand_lu[ns];
+    bin = -1; lp = 0.0;
+    if (tid < cnt) { bin = cand_bin[ns * fp.cap + tid]; lp = cand_lp[ns * fp.cap + tid]; }
+  };
+  int nx_bin; double nx_lp, nx_lu;
+  load_cand(0, nx_bin, nx_lp, nx_lu);
+  __syncthreads();
+  int bin_prev = -1, bin_cur = (nx_bin >= 0 && nx_bin < nb) ? nx_bin : -1;
+  if (bin_cur >= 0) olp3[bin_cur] = nx_lp;
+  double lu = nx_lu;
+  if (T > 1) load_cand(1, nx_bin, nx_lp, nx_lu);
+  __syncthreads();
+
+  // targets of this thread: bin tid (+ a multiple of the block size); when one pass covers the range, the last
+  // wave takes the top 64 bins so that the high-edge targets share one wave
+  const bool single = nb <= kVitThreads && nb >= 128;
   for (int t = 0; t < T; ++t) {
-    // ---- log observation column: voiced bins from the candidate list, one value for every unvoiced bin
-    for (int b = tid; b < nb; b += kVitThreads) olp[b] = c0;
-    __syncthreads();
-    if (pf_bin >= 0 && pf_bin < nb) olp[pf_bin] = log(pf_prob + fp.tiny);
-    const double lu = log((1.0 - pf_vp) / (double)nb + fp.tiny);
-    if (t + 1 < T) {                                     // issue the next step's loads now
-      const int64_t ns = cd.frame_base + t + 1;
-      pf_cnt = cand_cnt[ns]; pf_vp = cand_vp[ns];
-      pf_bin = -1;
-      if (tid < pf_cnt) { pf_bin = cand_bin[ns * fp.cap + tid]; pf_prob = cand_prob[ns * fp.cap + tid]; }
+    stamp(-1);
+    const double* olp = olp3 + (t % 3) * nb;
+    // ---- the next step's observation column, the one before's taken back
+    if (bin_prev >= 0) olp3[((t + 2) % 3) * nb + bin_prev] = c0;
+    int bin_next = -1; double lu_next = 0.0;
+    if (t + 1 < T) {
+      bin_next = (nx_bin >= 0 && nx_bin < nb) ? nx_bin : -1;
+      if (bin_next >= 0) olp3[((t + 1) % 3) * nb + bin_next] = nx_lp;
+      lu_next = nx_lu;
+      if (t + 2 < T) load_cand(t + 2, nx_bin, nx_lp, nx_lu);
     }
-    __syncthreads();
+    stamp(0);
     double* const vout = vclip + (size_t)t * S;
-    if (t == 0) {
-      for (int j = tid; j < S; j += kVitThreads) { const double x = j < nb ? olp[j] + c0 : lu + lpi_u; vcur[j] = x; vout[j] = x; }
-    } else {
-      double gmax = 0.0; int garg = 0;
-      if (!(fp.debug & 2)) block_argmax(vprev, gmax, garg);
+    double pbv = -INFINITY; int pbi = 1 << 30;          // this thread's (max, lowest index) of the new column
+    auto note = [&](double xv, double xu, int jb) {
+      if (xv > pbv || (xv == pbv && jb < pbi)) { pbv = xv; pbi = jb; }
+      if (xu > pbv || (xu == pbv && nb + jb < pbi)) { pbv = xu; pbi = nb + jb; }
+    };
+    double gmax = 0.0; int garg = 0;
+    if (t > 0) {
+      get_best(t & 1, gmax, garg);
       if (tid == 0) { VitBest vb; vb.value = gmax; vb.arg = garg; vb.pad = 0; bclip[t] = vb; }
-      const int gb = garg >= nb ? garg - nb : garg;
-      const double* v0 = vprev;                          // voiced sources
-      const double* v1 = vprev + nb;                     // unvoiced sources
-      // one thread per pitch bin jb: both targets (voiced jb, unvoiced jb) from one walk over the band
-      for (int jb = tid; jb < nb; jb += kVitThreads) {
-        const int blo = jb - band < 0 ? 0 : jb - band, bhi = jb + band > nb - 1 ? nb - 1 : jb + band;
+    }
+    stamp(1);
+    const int gb = garg >= nb ? garg - nb : garg;
+    const double* m0 = vprev;                            // voiced sources, main cells
+    const double* m1 = vprev + VM;                       // unvoiced
+    const double* e0 = vprev + 2 * VM;                   // edge-class sources
+    const double* e1 = e0 + 2 * band;
+    for (int base = 0; base < nb; base += kVitThreads) {
+      int jb = base + tid;
+      bool live = jb < nb;
+      if (single) {
+        if (wave == NW - 1) { jb = nb - 64 + lane; live = true; }
+        else live = tid < nb - 64;
+      }
+      if (!__any(live)) continue;
+      const int jc = live ? jb : band;                   // idle lanes walk somewhere harmless
+      double xv, xu;
+      if (t == 0) {
+        xv = olp[jc] + c0; xu = lu + lpi_u;
+      } else {
         double bv = -INFINITY, bu = -INFINITY;           // best move into (voiced jb), (unvoiced jb)
-        // log-transition entry of source b -> target jb is LT[rc(b)][jb - b + band]; rc = 0 for interior sources,
-        // 1 + b below `band`, 1 + band + (nb - 1 - b) within `band` of the top: three runs of b, each with a
-        // constant table stride
-        auto scan = [&](int b0, int b1, int idx0, int stride) {
-          const double* ps = LTs + idx0;
-          const double* pw = LTw + idx0;
-          for (int b = b0; b <= b1; ++b) {
-            const double a0 = v0[b], a1 = v1[b];
-            const double ws = *ps, ww = *pw;
-            ps += stride; pw += stride;
-            bv = fmax(bv, fmax(a0 + ws, a1 + ww));
-            bu = fmax(bu, fmax(a0 + ww, a1 + ws));
-          }
-        };
-        if (fp.debug & 1) {
-          // ablation: no band walk
-        } else if (jb >= 2 * band && jb <= nb - 1 - 2 * band) {  // every source row is an interior row
-          const double* p0 = v0 + (jb - band);
-          const double* p1 = v1 + (jb - band);
+        if (!(fp.debug & 1)) {
+          const double* p0 = m0 + jc;                    // cells of the sources jc - band .. jc + band
+          const double* p1 = m1 + jc;
 #pragma unroll 4
           for (int e = 0; e < width; ++e) {
             const double a0 = p0[e], a1 = p1[e];
@@ -570,29 +657,53 @@ __global__ __launch_bounds__(kVitThreads, 2) void k_f0_viterbi(const ClipDesc* _
             bv = fmax(bv, fmax(a0 + ws, a1 + ww));
             bu = fmax(bu, fmax(a0 + ww, a1 + ws));
           }
-        } else {
-          const int lo_end = bhi < band - 1 ? bhi : band - 1;                    // sources with rc = 1 + b
-          if (blo <= lo_end) scan(blo, lo_end, (1 + blo) * width + (jb - blo + band), width - 1);
-          const int mid0 = blo > band ? blo : band, mid1 = bhi < nb - 1 - band ? bhi : nb - 1 - band;
-          if (mid0 <= mid1) scan(mid0, mid1, jb - mid0 + band, -1);
-          const int hi0 = blo > nb - band ? blo : nb - band;                     // sources with rc = 1 + band + (nb - 1 - b)
-          if (hi0 <= bhi) scan(hi0, bhi, (1 + band + (nb - 1 - hi0)) * width + (jb - hi0 + band), -(width + 1));
+          // edge-class source b -> target jb: LT[rc][jb - b + band], rc = 1 + b (low), 1 + band + (nb - 1 - b)
+          // (high).  A lane whose target is out of that source's band reads a log(0) cell instead (row 1,
+          // entry 0): harmless, the best out-of-band move below is at least as good.
+          auto edge_pass = [&](int b, int k, int rc) {
+            const int d = jc - b + band;
+            const int idx = (unsigned)d <= (unsigned)(2 * band) ? rc * width + d : width;
+            const double a0 = e0[k], a1 = e1[k];
+            const double ws = LTs[idx], ww = LTw[idx];
+            bv = fmax(bv, fmax(a0 + ws, a1 + ww));
+            bu = fmax(bu, fmax(a0 + ww, a1 + ws));
+          };
+          if (!(fp.debug & 4)) {
+            if (__any(live && jb < 2 * band)) {
+#pragma unroll 5
+              for (int b = 0; b < band; ++b) edge_pass(b, b, 1 + b);
+            }
+            if (__any(live && jb > nb - 1 - 2 * band)) {
+#pragma unroll 5
+              for (int k = 0; k < band; ++k) edge_pass(nb - band + k, band + k, 2 * band - k);
+            }
+          }
         }
+        const int blo = jc - band < 0 ? 0 : jc - band, bhi = jc + band > nb - 1 ? nb - 1 : jc + band;
         if (gb < blo || gb > bhi) {                      // the best out-of-band source
           const double cand = gmax + c0;
           bv = fmax(bv, cand); bu = fmax(bu, cand);
         }
-        const double xv = olp[jb] + bv, xu = lu + bu;
-        vcur[jb] = xv; vcur[nb + jb] = xu;
+        xv = olp[jc] + bv; xu = lu + bu;
+      }
+      stamp(2);
+      if (live) {
+        put_value(vcur, jb, xv, xu);
         vout[jb] = xv; vout[nb + jb] = xu;
+        note(xv, xu, jb);
       }
     }
+    stamp(3);
+    put_partial((t + 1) & 1, pbv, pbi);
+    bin_prev = bin_cur; bin_cur = bin_next; lu = lu_next;
     double* tmp = vprev; vprev = vcur; vcur = tmp;
+    stamp(4);
     __syncthreads();
+    stamp(5);
   }
   // ---- last state, then back-tracking: the arg-max of the one state on the path, a step at a time
   double gmax; int garg;
-  block_argmax(vprev, gmax, garg);
+  get_best(T & 1, gmax, garg);
   uint16_t* sts = states + cd.frame_base;
   __threadfence();
   __syncthreads();
@@ -633,6 +744,12 @@ __global__ __launch_bounds__(kVitThreads, 2) void k_f0_viterbi(const ClipDesc* _
   }
   __threadfence_block();
   __syncthreads();
+  stamp(6);
+  if constexpr (STAMP) {
+    if (clip == 0 && lane == 0)
+      printf("vit wave %d T %d: top %llu best %llu walk %llu tail %llu partial %llu barrier %llu backtrack %llu\n", wave, T,
+             ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+  }
   // ---- statistics over voiced frames (feature_extractor.py:97-107)
   auto block_sum = [&](double v) -> double {
     v = wave_sum_d(v);
@@ -755,14 +872,24 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
 
 hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const F0Tables& tb,
                              const F0Params& fp, const int32_t* cand_cnt, const double* cand_vp,
-                             const int16_t* cand_bin, const double* cand_prob, double* vrows, VitBest* vbest,
+                             const int16_t* cand_bin, const double* cand_prob, double* cand_lp, double* cand_lu,
+                             int64_t frames, double* vrows, VitBest* vbest,
                              uint16_t* states, double* out_stats, double* out_f0, const int64_t* f0_offsets,
                              int n_clips) {
+  hipLaunchKernelGGL(k_f0_logs, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, s, cand_cnt, cand_vp, cand_prob, cand_lp,
+                     cand_lu, frames, fp);
   const size_t lds = f0_viterbi_lds_bytes(fp);
-  hipError_t e = allow_lds(k_f0_viterbi, lds);
+  if (fp.debug & 8) {
+    hipError_t e = allow_lds(k_f0_viterbi<true>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_f0_viterbi<true>, dim3(n_clips), dim3(kVitThreads), lds, s, clips, info, tb, fp, cand_cnt,
+                       cand_bin, cand_lp, cand_lu, vrows, vbest, states, out_stats, out_f0, f0_offsets);
+    return hipGetLastError();
+  }
+  hipError_t e = allow_lds(k_f0_viterbi<false>, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_f0_viterbi, dim3(n_clips), dim3(kVitThreads), lds, s, clips, info, tb, fp, cand_cnt,
-                     cand_vp, cand_bin, cand_prob, vrows, vbest, states, out_stats, out_f0, f0_offsets);
+  hipLaunchKernelGGL(k_f0_viterbi<false>, dim3(n_clips), dim3(kVitThreads), lds, s, clips, info, tb, fp, cand_cnt,
+                     cand_bin, cand_lp, cand_lu, vrows, vbest, states, out_stats, out_f0, f0_offsets);
   return hipGetLastError();
 }
 
