@@ -124,6 +124,42 @@ def test_f0_other_frame_sizes(sr, n_fft, hop):
         ctx.close()
 
 
+@pytest.mark.parametrize("fmin,fmax,tones", [(100.0, 400.0, (150.0, 260.0)),      # 241 pitch bins
+                                             (200.0, 300.0, (220.0, 262.0)),      # 71 bins: every target is within 2 band of a range end
+                                             (50.0, 5000.0, (130.0, 310.0))])     # 798 bins: more than one target per Viterbi thread
+def test_f0_other_pitch_ranges(plan, fmin, fmax, tones):
+    """f0_min / f0_max other than the reference's C2..C7: other state counts for the Viterbi kernel (its target-to-wave
+    mapping, the edge-class sources, several targets per thread) and other lag ranges for the yin kernel."""
+    t = np.arange(int(SR * 0.8)) / SR
+    rng = np.random.default_rng(11)
+    clips = []
+    for f in tones:
+        ph = 2 * np.pi * f * t * (1 + 0.01 * np.sin(2 * np.pi * 4 * t))
+        c = 0.3 * np.sin(ph) + 0.08 * np.sin(2 * ph) + 0.004 * rng.standard_normal(t.size)
+        c[: SR // 10] = 0.004 * rng.standard_normal(SR // 10)                     # an unvoiced lead-in
+        clips.append(c.astype(np.float32))
+    lengths = np.array([c.size for c in clips], np.int64)
+    pad = (lengths + 3) // 4 * 4
+    offsets = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.int64)
+    buf = np.zeros(int(pad.sum()), np.float32)
+    for c, o in zip(clips, offsets):
+        buf[o:o + c.size] = c
+    out = plan.f0_batch(buf, offsets, lengths, fmin, fmax, flags=0, want_frames=True)
+    assert (out["status"] == 0).all()
+    for i, c in enumerate(clips):
+        T = 1 + c.size // 256
+        f0 = out["f0_flat"][out["f0_offsets"][i]: out["f0_offsets"][i] + T]
+        ref, _, _ = P.pyin(c, fmin, fmax, sr=SR, frame_length=1024, hop_length=256)
+        same = np.isnan(f0) == np.isnan(ref)
+        v = ~np.isnan(f0) & ~np.isnan(ref)
+        same[v] &= np.abs(f0[v] - ref[v]) <= 1e-9 * ref[v]
+        assert same.mean() >= 0.99, (fmin, fmax, i, same.mean(), np.flatnonzero(~same)[:12])
+        assert v.sum() >= 0.5 * T, (fmin, fmax, i, int(v.sum()))                  # the tone is found
+    # back on the default range the plan rebuilds its tables
+    out2 = plan.f0_batch(buf, offsets, lengths, P.C2_HZ, P.C7_HZ, flags=0)
+    assert (out2["status"] == 0).all()
+
+
 def test_f0_random_mixtures(plan):
     """Voiced / noisy / silent stretches in random order: onsets, offsets and octave ambiguities."""
     rng = np.random.default_rng(11)
