@@ -144,7 +144,11 @@ int afx_extract_batch(afx_plan* plan,
  *             (0, 0, 1, 0 when no frame is voiced -- the reference's own branch F:103-107)
  *   out_status host int32[n_clips]: AFX_CLIP_OK or AFX_CLIP_NONFINITE
  *   out_f0    NULL, or host double buffer: clip i's per-frame f0 (NaN = unvoiced) in
- *             out_f0[f0_offsets[i] .. + T_i), T_i = 1 + kept_length_i / hop
+ *             out_f0[f0_offsets[i] .. + T_i), T_i = 1 + kept_length_i / hop; the rest of the clip's
+ *             1 + length_i / hop slots (frames trimmed away) is set to NaN
+ * Device workspace inside the plan: about 14 KB per frame (the Viterbi value columns, 2 * n_bins
+ * doubles per frame, are kept for back-tracking); batches are processed in chunks of at most
+ * 1.28 M frames (about 18 GB).
  * Float64 throughout, except the running frame energy, which numpy accumulates in
  * float32 and which is reproduced add for add. */
 int afx_f0_batch(afx_plan* plan,
