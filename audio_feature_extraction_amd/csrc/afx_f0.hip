@@ -73,10 +73,12 @@ size_t f0_energy_lds_bytes(const F0Params& fp) {
   return (span + span / fp.hop + 8) * 4 + (size_t)fp.n_tau * (fp.epb + 1) * 4;
 }
 
-__global__ __launch_bounds__(64) void k_f0_energy(const float* __restrict__ ysig,
-                                                  const ClipDesc* __restrict__ clips,
-                                                  const ClipInfo* __restrict__ info,
-                                                  float* __restrict__ energy, F0Params fp) {
+constexpr int kEnergyWaves = 4;       // waves per workgroup of k_f0_energy
+
+__global__ __launch_bounds__(64 * kEnergyWaves) void k_f0_energy(const float* __restrict__ ysig,
+                                                                 const ClipDesc* __restrict__ clips,
+                                                                 const ClipInfo* __restrict__ info,
+                                                                 float* __restrict__ energy, F0Params fp) {
   extern __shared__ float sme[];
   const int clip = blockIdx.y;
   const ClipInfo ci = info[clip];
@@ -86,52 +88,77 @@ __global__ __launch_bounds__(64) void k_f0_energy(const float* __restrict__ ysig
   if (t0 >= T) return;
   const ClipDesc cd = clips[clip];
   const int64_t np = ci.end - ci.start;
-  const int lane = threadIdx.x;
+  constexpr int NT = 64 * kEnergyWaves;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int span = (E - 1) * hop + fp.W + fp.n_tau;
   float* S = sme;
   float* H = sme + (span + span / hop + 8);
   const int hs = E + 1;
   const int64_t g0 = (int64_t)t0 * hop - fp.n_fft / 2;
   const float* y = ysig + cd.off;
-  for (int i = lane; i < span; i += 64) {
+  for (int i = tid; i < span; i += NT) {
     const int64_t g = g0 + i;
     S[i + i / hop] = (g >= 0 && g < np) ? y[g] : 0.f;
   }
   __syncthreads();
-  if (lane < E && t0 + lane < T) {
+  // The chain is serial per frame, one lane each; a wave's time is its instruction count whatever the number of
+  // active lanes, so the chain is split into its three regimes (history kept / nothing stored / difference formed)
+  // and into runs between the index pads, each an unrolled loop with immediate offsets and no per-step tests.
+  // Four waves share a block's frames: staging and the transposed write-out go four times faster, the chains run
+  // on the four SIMDs side by side (sixteen waves of four lanes were slower: the chain is issued per wave).
+  const int fw = E / kEnergyWaves > 0 ? E / kEnergyWaves : 1;      // frames per wave
+  const int fr = wave * fw + lane;                                 // this lane's frame of the block
+  if (lane < fw && fr < E && t0 + fr < T) {
     float e = 0.f;
-    const int nsteps = fp.W + fp.n_tau;
-    // padded index of sample lane * hop + n is lane * (hop + 1) + n + n / hop: n / hop is carried, not divided.
-    // Eight samples (and the eight history values they meet) are fetched before the serial float32 chain touches
-    // them, so the chain costs its additions, not an LDS round trip per step.
-    int sidx = lane * (hop + 1), r = 0;
-    for (int n0 = 0; n0 < nsteps; n0 += 8) {
-      float yv[8], hv[8];
+    const int W = fp.W, n_tau = fp.n_tau;                          // n_tau <= W (max_period <= n_fft - W - 1)
+    // padded index of sample fr * hop + n is fr * (hop + 1) + n + n / hop
+    auto seg = [&](int nb, int ne, auto phase) {                   // steps [nb, ne) inside one hop-sized run
+      constexpr int PH = decltype(phase)::value;
+      const float* sp = S + fr * (hop + 1) + nb / hop;
+      float* hk = H + fr;                                          // history / result column of this frame
+      int n = nb;
+      for (; n + 8 <= ne; n += 8) {
+        float yv[8], hv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        yv[u] = (n0 + u < nsteps) ? S[sidx] : 0.f;
-        ++sidx;
-        if (++r == hop) { r = 0; ++sidx; }
-        const int tau = n0 + u - fp.W;
-        hv[u] = (tau >= 0 && n0 + u < nsteps) ? H[tau * hs + lane] : 0.f;
-      }
+        for (int u = 0; u < 8; ++u) {
+          yv[u] = sp[n + u];
+          if constexpr (PH == 3) hv[u] = hk[(n + u - W) * hs];
+        }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int n = n0 + u;
-        if (n < nsteps) {
+        for (int u = 0; u < 8; ++u) {
           e = sq_acc(e, yv[u]);
-          if (n < fp.n_tau) H[n * hs + lane] = e;
-          if (n >= fp.W) {
+          if constexpr (PH == 1) hk[(n + u) * hs] = e;
+          if constexpr (PH == 3) {
             float d = e - hv[u];
             if (fabsf(d) < 1e-6f) d = 0.f;
-            H[(n - fp.W) * hs + lane] = d;
+            hk[(n + u - W) * hs] = d;
           }
         }
       }
-    }
+      for (; n < ne; ++n) {
+        e = sq_acc(e, sp[n]);
+        if constexpr (PH == 1) hk[n * hs] = e;
+        if constexpr (PH == 3) {
+          float d = e - hk[(n - W) * hs];
+          if (fabsf(d) < 1e-6f) d = 0.f;
+          hk[(n - W) * hs] = d;
+        }
+      }
+    };
+    auto range = [&](int a, int b, auto phase) {
+      while (a < b) {
+        const int stop = (a / hop + 1) * hop;
+        const int ne = stop < b ? stop : b;
+        seg(a, ne, phase);
+        a = ne;
+      }
+    };
+    range(0, n_tau, std::integral_constant<int, 1>());             // e[n] kept for n < n_tau
+    range(n_tau, W, std::integral_constant<int, 2>());
+    range(W, W + n_tau, std::integral_constant<int, 3>());         // e[W + tau] - e[tau]
   }
   __syncthreads();
-  for (int f = 0; f < E && t0 + f < T; ++f) {
+  for (int f = wave; f < E && t0 + f < T; f += kEnergyWaves) {
     float* row = energy + (cd.frame_base + t0 + f) * (int64_t)fp.n_tau_pad;
     for (int tau = lane; tau < fp.n_tau; tau += 64) row[tau] = H[tau * hs + f];
   }
@@ -843,7 +870,7 @@ hipError_t launch_f0_energy(hipStream_t s, const float* ysig, const ClipDesc* cl
   hipError_t e = allow_lds(k_f0_energy, lds);
   if (e != hipSuccess) return e;
   dim3 grid((max_tmax + fp.epb - 1) / fp.epb, n_clips);
-  hipLaunchKernelGGL(k_f0_energy, grid, dim3(64), lds, s, ysig, clips, info, energy, fp);
+  hipLaunchKernelGGL(k_f0_energy, grid, dim3(64 * kEnergyWaves), lds, s, ysig, clips, info, energy, fp);
   return hipGetLastError();
 }
 
