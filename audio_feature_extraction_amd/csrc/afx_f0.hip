@@ -337,29 +337,43 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
         pr[c] = 0.0;
       }
       F0_WAVE_SYNC();
-      // ---- probabilities: for every threshold, a Boltzmann prior over the troughs below it
+      // ---- probabilities: for every threshold, a Boltzmann prior over the troughs below it.  The thresholds
+      // rise, so the set of troughs below can only grow: once it holds every trough that the last threshold
+      // undercuts, ranks, count and prior stay what they are and the remaining thresholds only add their beta mass.
+      int n_all = 0;
+#pragma unroll
+      for (int c = 0; c < CSM; ++c)
+        if (c < CS) n_all += __popcll(__ballot(tr[c] && h[c] < Tthr[kF0Thresholds]));
+      int pos[CSM];
+      double ex[CSM];
+#pragma unroll
+      for (int c = 0; c < CSM; ++c) { pos[c] = -1; ex[c] = 0.0; }
+      double fact = 0.0;
+      bool stable = false;
       for (int k = 1; k <= ((fp.debug & 8) ? 4 : kF0Thresholds); ++k) {
-        const double thr = Tthr[k];
-        // positions first (no memory), then one batch of table reads: a read under `if (below)` would put a
-        // dependent LDS round trip into every slot of every threshold
-        int pos[CSM];
-        int n = 0;
+        if (!stable) {
+          const double thr = Tthr[k];
+          // positions first (no memory), then one batch of table reads: a read under `if (below)` would put a
+          // dependent LDS round trip into every slot of every threshold
+          int n = 0;
 #pragma unroll
-        for (int c = 0; c < CSM; ++c) {
-          pos[c] = -1;
-          if (c < CS) {
-            const bool below = tr[c] && h[c] < thr;
-            const unsigned long long m = __ballot(below);
-            pos[c] = below ? n + lanes_below(m) : -1;
-            n += __popcll(m);
+          for (int c = 0; c < CSM; ++c) {
+            pos[c] = -1;
+            if (c < CS) {
+              const bool below = tr[c] && h[c] < thr;
+              const unsigned long long m = __ballot(below);
+              pos[c] = below ? n + lanes_below(m) : -1;
+              n += __popcll(m);
+            }
           }
-        }
-        if (n == 0) continue;
-        const double fact = Tfact[n], bk = Tbeta[k - 1];
-        double ex[CSM];
+          if (n == 0) continue;
+          fact = Tfact[n];
 #pragma unroll
-        for (int c = 0; c < CSM; ++c)
-          if (c < CS) ex[c] = Texp[pos[c] < 0 ? 0 : pos[c]];
+          for (int c = 0; c < CSM; ++c)
+            if (c < CS) ex[c] = Texp[pos[c] < 0 ? 0 : pos[c]];
+          stable = n == n_all;
+        }
+        const double bk = Tbeta[k - 1];
 #pragma unroll
         for (int c = 0; c < CSM; ++c)
           if (c < CS && pos[c] >= 0) pr[c] += (fact * ex[c]) * bk;
@@ -529,7 +543,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   const int clip = blockIdx.x;
   const ClipInfo ci = info[clip];
   double* st = out_stats + (size_t)clip * 4;
-  // AFX_F0_DEBUG & 8: per-phase cycle counts of workgroup 0, printed per wave (developer aid)
+  // AFX_F0_DEBUG & 16: per-phase cycle counts of workgroup 0, printed per wave (developer aid)
   unsigned long long ph[8] = {}, ph_t = 0;
   auto stamp = [&](int i) {
     if constexpr (STAMP) {
@@ -906,7 +920,7 @@ hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInf
   hipLaunchKernelGGL(k_f0_logs, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, s, cand_cnt, cand_vp, cand_prob, cand_lp,
                      cand_lu, frames, fp);
   const size_t lds = f0_viterbi_lds_bytes(fp);
-  if (fp.debug & 8) {
+  if (fp.debug & 16) {
     hipError_t e = allow_lds(k_f0_viterbi<true>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_f0_viterbi<true>, dim3(n_clips), dim3(kVitThreads), lds, s, clips, info, tb, fp, cand_cnt,
