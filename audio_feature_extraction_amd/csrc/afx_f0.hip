@@ -55,6 +55,36 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {       // s
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 
+#define F0_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, false)
+template <int CTRL> __device__ __forceinline__ double dpp_dd(double v) {
+  return __hiloint2double(F0_DPP_I(__double2hiint(v), CTRL), F0_DPP_I(__double2loint(v), CTRL));
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {         // uniform result
+  v = fmax(v, dpp_dd<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = fmax(v, dpp_dd<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = fmax(v, dpp_dd<0x141>(v));     // row_half_mirror
+  v = fmax(v, dpp_dd<0x140>(v));     // row_mirror
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  auto rl = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l)); };
+  return fmax(fmax(rl(0), rl(16)), fmax(rl(32), rl(48)));
+}
+__device__ __forceinline__ int wave_min_dpp(int v) {               // uniform result
+  v = min(v, F0_DPP_I(v, 0xB1));
+  v = min(v, F0_DPP_I(v, 0x4E));
+  v = min(v, F0_DPP_I(v, 0x141));
+  v = min(v, F0_DPP_I(v, 0x140));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+typedef const double __attribute__((address_space(4))) cdouble_k;   // constant address space: uniform reads become s_load
+__device__ __forceinline__ cdouble_k* as_constant(const double* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (cdouble_k*)p;
+#pragma clang diagnostic pop
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_f0_energy: energy_frames[tau] = e[W + tau] - e[tau], e = np.cumsum(frame ** 2) in float32.
 // The chain is serial per frame, so a lane takes a frame; the block's samples sit in LDS once
@@ -360,46 +390,61 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
         pr[c] = 0.0;
       }
       F0_WAVE_SYNC();
-      // ---- probabilities: for every threshold, a Boltzmann prior over the troughs below it.  The thresholds
-      // rise, so the set of troughs below can only grow: once it holds every trough that the last threshold
-      // undercuts, ranks, count and prior stay what they are and the remaining thresholds only add their beta mass.
-      int n_all = 0;
+      // ---- probabilities: for every threshold, a Boltzmann prior over the troughs below it.  The thresholds rise,
+      // so the set of troughs below one only grows, and it changes at no more than n_troughs of the 100 thresholds:
+      // a trough enters at kin = the first threshold above its height; between two entry events ranks, count and
+      // prior are constant, so they are formed once per run and the thresholds of the run only add prior * beta[k],
+      // one after the other as before (the sums are bit-identical to re-ranking at every threshold; librosa takes
+      // them as a BLAS dot, whose order is not pinned, and a strongly voiced frame's total decides between an
+      // unvoiced observation of 0 and of 2e-19 -- see DESIGN.md 7 -- so the order is not touched).
+      const int kmax = (fp.debug & 8) ? 4 : kF0Thresholds;
+      int kin[CSM];
 #pragma unroll
-      for (int c = 0; c < CSM; ++c)
-        if (c < CS) n_all += __popcll(__ballot(tr[c] && h[c] < Tthr[kF0Thresholds]));
-      int pos[CSM];
-      double ex[CSM];
-#pragma unroll
-      for (int c = 0; c < CSM; ++c) { pos[c] = -1; ex[c] = 0.0; }
-      double fact = 0.0;
-      bool stable = false;
-      for (int k = 1; k <= ((fp.debug & 8) ? 4 : kF0Thresholds); ++k) {
-        if (!stable) {
-          const double thr = Tthr[k];
-          // positions first (no memory), then one batch of table reads: a read under `if (below)` would put a
-          // dependent LDS round trip into every slot of every threshold
-          int n = 0;
-#pragma unroll
-          for (int c = 0; c < CSM; ++c) {
-            pos[c] = -1;
-            if (c < CS) {
-              const bool below = tr[c] && h[c] < thr;
-              const unsigned long long m = __ballot(below);
-              pos[c] = below ? n + lanes_below(m) : -1;
-              n += __popcll(m);
-            }
-          }
-          if (n == 0) continue;
-          fact = Tfact[n];
-#pragma unroll
-          for (int c = 0; c < CSM; ++c)
-            if (c < CS) ex[c] = Texp[pos[c] < 0 ? 0 : pos[c]];
-          stable = n == n_all;
+      for (int c = 0; c < CSM; ++c) {
+        kin[c] = 1 << 20;
+        if (tr[c]) {
+          int kk = (int)(fmin(fmax(h[c], 0.0), 2.0) * (double)kF0Thresholds) + 1;
+          kk = kk < 1 ? 1 : (kk > kF0Thresholds ? kF0Thresholds : kk);
+          while (kk > 1 && h[c] < Tthr[kk - 1]) --kk;                       // first k with h < thr[k]
+          while (kk <= kF0Thresholds && !(h[c] < Tthr[kk])) ++kk;
+          if (kk <= kF0Thresholds) kin[c] = kk;
         }
-        const double bk = Tbeta[k - 1];
+      }
+      auto next_event = [&](int after) {                                     // smallest kin > after (wave-uniform)
+        int m = 1 << 20;
 #pragma unroll
         for (int c = 0; c < CSM; ++c)
-          if (c < CS && pos[c] >= 0) pr[c] += (fact * ex[c]) * bk;
+          if (c < CS && kin[c] > after) m = min(m, kin[c]);
+        return wave_min_dpp(m);
+      };
+      int ka = next_event(0);
+      while (ka <= kmax) {
+        int kb = next_event(ka);                                             // the run is ka .. kb - 1
+        if (kb > kmax + 1) kb = kmax + 1;
+        int pos[CSM];
+        int n = 0;
+#pragma unroll
+        for (int c = 0; c < CSM; ++c) {
+          pos[c] = -1;
+          if (c < CS) {
+            const bool below = kin[c] <= ka;
+            const unsigned long long m = __ballot(below);
+            pos[c] = below ? n + lanes_below(m) : -1;
+            n += __popcll(m);
+          }
+        }
+        const double fact = Tfact[n];
+        double fe[CSM];                                                      // prior of this run; 0 for a trough not below
+#pragma unroll
+        for (int c = 0; c < CSM; ++c) fe[c] = (c < CS && pos[c] >= 0) ? fact * Texp[pos[c]] : 0.0;
+#pragma unroll 4
+        for (int k = ka; k < kb; ++k) {
+          const double bk = Tbeta[k - 1];
+#pragma unroll
+          for (int c = 0; c < CSM; ++c)
+            if (c < CS) pr[c] += fe[c] * bk;
+        }
+        ka = kb;
       }
       // global minimum (first occurrence) collects the mass of the thresholds it does not undercut
       double hm = INFINITY;
@@ -489,36 +534,6 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
 // (numpy's argmax rule) -- bit-identical to forming all pointers up front.
 // ---------------------------------------------------------------------------------------------
 constexpr int kVitThreads = 640;
-
-#define F0_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, false)
-template <int CTRL> __device__ __forceinline__ double dpp_dd(double v) {
-  return __hiloint2double(F0_DPP_I(__double2hiint(v), CTRL), F0_DPP_I(__double2loint(v), CTRL));
-}
-__device__ __forceinline__ double wave_max_dpp(double v) {         // uniform result
-  v = fmax(v, dpp_dd<0xB1>(v));      // quad_perm [1,0,3,2]
-  v = fmax(v, dpp_dd<0x4E>(v));      // quad_perm [2,3,0,1]
-  v = fmax(v, dpp_dd<0x141>(v));     // row_half_mirror
-  v = fmax(v, dpp_dd<0x140>(v));     // row_mirror
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  auto rl = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l)); };
-  return fmax(fmax(rl(0), rl(16)), fmax(rl(32), rl(48)));
-}
-__device__ __forceinline__ int wave_min_dpp(int v) {               // uniform result
-  v = min(v, F0_DPP_I(v, 0xB1));
-  v = min(v, F0_DPP_I(v, 0x4E));
-  v = min(v, F0_DPP_I(v, 0x141));
-  v = min(v, F0_DPP_I(v, 0x140));
-  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-
-typedef const double __attribute__((address_space(4))) cdouble_k;   // constant address space: uniform reads become s_load
-__device__ __forceinline__ cdouble_k* as_constant(const double* p) {
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-  return (cdouble_k*)p;
-#pragma clang diagnostic pop
-}
 
 struct VitLds { size_t v, olp, lt, red, total; };
 __host__ __device__ inline VitLds vit_lds(const F0Params& fp) {
