@@ -15,6 +15,7 @@ traffic.  Two deployment shapes share the partition/gather helpers here:
 from __future__ import annotations
 
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 from typing import Any, Dict, List, Sequence, Tuple
 
@@ -87,6 +88,7 @@ def _pack(clips: List[np.ndarray], dtype) -> Tuple[np.ndarray, np.ndarray, np.nd
     return buf, offsets, lengths
 
 
+LAST_TIMING: Dict[str, Any] = {}     # seconds per phase of the last process_files call (developer aid)
 WORKERS_PER_GPU = 3     # sub-batches in flight per GPU (own context / stream / thread): copies, the bandwidth-bound
                         # kernels and the host round trip of one hide under the frame kernel of another
 
@@ -99,6 +101,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
     if n == 0:
         return []
     devices = extractor._devices()
+    t_start = time.perf_counter()
     decoded: List[Any] = [None] * n
     errors: List[Any] = [None] * n
 
@@ -112,6 +115,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
     with ThreadPoolExecutor(max(1, min(16, n))) as ex:
         list(ex.map(dec, range(n)))
 
+    t_decoded = time.perf_counter()
     ok = [i for i in range(n) if decoded[i] is not None]
     K = extractor.n_mfcc
     stats = np.zeros((n, 4 * K + 3), np.float32)
@@ -162,6 +166,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
     for t in threads:
         t.join()
 
+    t_gpu = time.perf_counter()
     results: List[Dict[str, Any]] = []
     from .core.feature_extractor import _status_error
     for i, f in enumerate(files):
@@ -177,4 +182,5 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
         f0d = extractor._f0_to_dict(f0s[i]) if want_f0 else extractor.extract_f0(decoded[i][1])
         results.append({"file_path": str(f), **f0d, **mfcc, **energy})
         log.info(f"成功處理文件: {name}")
+    LAST_TIMING.update(decode=t_decoded - t_start, device=t_gpu - t_decoded, dicts=time.perf_counter() - t_gpu, files=n)
     return results
