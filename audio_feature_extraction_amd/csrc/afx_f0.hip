@@ -653,10 +653,17 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   // so that *every* target walks its band with the interior row's weights and no masking (a missing source reads
   // -inf), and only the two waves that own targets within 2 band of a range end add the edge-class sources, one
   // uniform table row per source.
+  // What the columns hold is already folded over the source's voicing: with d = log(.99) - log(.01) (taken from the
+  // table: stay minus switch entry), a move into a voiced target costs max(v_voiced, v_unvoiced - d) + stay, into an
+  // unvoiced one max(v_voiced - d, v_unvoiced) + stay, so a band entry is one add and one max per target instead of
+  // two each.  (v_unvoiced - d) + stay is (v_unvoiced + switch) up to the rounding of d -- at most an ulp of the
+  // value; the backward pass, which decides the path, takes the arg-max of the recurrence's own sums.)
+  const double dsw = tb.lt[band] - tb.lt[(size_t)width * width + band];
   auto put_value = [&](double* col, int jb, double xv, double xu) {
-    if (jb < band) { col[2 * VM + jb] = xv; col[2 * VM + 2 * band + jb] = xu; }
-    else if (jb >= nb - band) { const int k = band + jb - (nb - band); col[2 * VM + k] = xv; col[2 * VM + 2 * band + k] = xu; }
-    else { col[band + jb] = xv; col[VM + band + jb] = xu; }
+    const double cv = fmax(xv, xu - dsw), cu = fmax(xv - dsw, xu);
+    if (jb < band) { col[2 * VM + jb] = cv; col[2 * VM + 2 * band + jb] = cu; }
+    else if (jb >= nb - band) { const int k = band + jb - (nb - band); col[2 * VM + k] = cv; col[2 * VM + 2 * band + k] = cu; }
+    else { col[band + jb] = cv; col[VM + band + jb] = cu; }
   };
 
   // Observation columns: three LDS columns in rotation, all log(0) except where a step's candidates were
@@ -708,8 +715,8 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
     }
     stamp(1);
     const int gb = garg >= nb ? garg - nb : garg;
-    const double* m0 = vprev;                            // voiced sources, main cells
-    const double* m1 = vprev + VM;                       // unvoiced
+    const double* m0 = vprev;                            // folded for voiced targets, main cells
+    const double* m1 = vprev + VM;                       // folded for unvoiced targets
     const double* e0 = vprev + 2 * VM;                   // edge-class sources
     const double* e1 = e0 + 2 * band;
     for (int base = 0; base < nb; base += kVitThreads) {
@@ -731,10 +738,9 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
           const double* p1 = m1 + jc;
 #pragma unroll 4
           for (int e = 0; e < width; ++e) {
-            const double a0 = p0[e], a1 = p1[e];
-            const double ws = kk[2 * e], ww = kk[2 * e + 1];
-            bv = fmax(bv, fmax(a0 + ws, a1 + ww));
-            bu = fmax(bu, fmax(a0 + ww, a1 + ws));
+            const double ws = kk[2 * e];
+            bv = fmax(bv, p0[e] + ws);
+            bu = fmax(bu, p1[e] + ws);
           }
           // edge-class source b -> target jb: LT[rc][jb - b + band], rc = 1 + b (low), 1 + band + (nb - 1 - b)
           // (high).  A lane whose target is out of that source's band reads a log(0) cell instead (row 1,
@@ -742,10 +748,9 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
           auto edge_pass = [&](int b, int k, int rc) {
             const int d = jc - b + band;
             const int idx = (unsigned)d <= (unsigned)(2 * band) ? rc * width + d : width;
-            const double a0 = e0[k], a1 = e1[k];
-            const double ws = LTs[idx], ww = LTw[idx];
-            bv = fmax(bv, fmax(a0 + ws, a1 + ww));
-            bu = fmax(bu, fmax(a0 + ww, a1 + ws));
+            const double ws = LTs[idx];
+            bv = fmax(bv, e0[k] + ws);
+            bu = fmax(bu, e1[k] + ws);
           };
           if (!(fp.debug & 4)) {
             if (__any(live && jb < 2 * band)) {

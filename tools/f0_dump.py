@@ -1,0 +1,26 @@
+"""Dumps per-frame f0 of n synthetic clips (half of them 'speechy') to an .npy: python tools/f0_dump.py out.npy [n]
+(used to compare two builds of libafx.so through AFX_LIB)."""
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
+from audio_feature_extraction_amd import _native as N
+from audio_feature_extraction_amd.synth import make_clip
+out_path = sys.argv[1]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+clips = [make_clip(i, 22050, 4.0, speechy=bool(i & 1)) for i in range(n)]
+rng = np.random.default_rng(1)
+t = np.arange(int(22050 * 3.0)) / 22050
+for i in range(n // 2):                                  # voiced material: vibrato tones with harmonics and noise
+    f = float(rng.uniform(80, 900))
+    ph = 2 * np.pi * np.cumsum(f * (1 + 0.02 * np.sin(2 * np.pi * rng.uniform(3, 7) * t))) / 22050
+    clips.append((0.3 * np.sin(ph) + 0.1 * np.sin(2 * ph) + 0.05 * np.sin(3 * ph) + rng.uniform(0.001, 0.05) * rng.standard_normal(t.size)).astype(np.float32))
+lengths = np.array([c.size for c in clips], np.int64)
+pad = (lengths + 3) // 4 * 4
+offsets = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.int64)
+buf = np.zeros(int(pad.sum()), np.float32)
+for c, o in zip(clips, offsets):
+    buf[o:o + c.size] = c
+ctx = N.Context(0); plan = N.Plan(ctx, N.make_params(22050, 1024, 256, 13))
+out = plan.f0_batch(buf, offsets, lengths, 65.40639132514966, 2093.004522404789, want_frames=True)
+np.save(out_path, out["f0_flat"])
+print(os.environ.get("AFX_LIB", "default"), "frames", out["f0_flat"].size, "voiced", int((~np.isnan(out["f0_flat"])).sum()))
