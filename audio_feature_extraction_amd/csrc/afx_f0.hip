@@ -1,5 +1,5 @@
 // extract_f0 on MI355X: librosa.pyin at the reference's call site
-// (audio_feature_extraction_toolkit/core/feature_extractor.py:87-94) as three kernels over the
+// (audio_feature_extraction_toolkit/core/feature_extractor.py:87-94) as four kernels over the
 // preprocessed signal.  Everything that decides a pitch is float64, as in the pinned numpy stack;
 // the one float32 piece -- the running frame energy, a sequential np.cumsum of a float32 array --
 // is reproduced add for add, because near a trough the difference function is smaller than its
@@ -8,8 +8,14 @@
 //   k_f0_yin      one wave per frame: autocorrelation (direct, float64), difference function,
 //                 cumulative-mean normalisation, troughs, threshold/Boltzmann/Beta probabilities,
 //                 parabolic refinement, pitch bins -> a sparse observation column per frame
+//   k_f0_logs     the log observation values the Viterbi pass scatters (kept out of its step loop)
 //   k_f0_viterbi  one workgroup per clip: log-domain Viterbi over 2 x n_bins states with the banded
-//                 transition matrix, back-tracking, f0 statistics (feature_extractor.py:97-114)
+//                 transition matrix -- value-only forward pass, one barrier per step, the arg-max
+//                 recomputed along the path while back-tracking -- and the f0 statistics
+//                 (feature_extractor.py:97-114)
+// A wave issues one instruction per ~9 cycles on this part and two waves per SIMD one per ~4.6
+// (tools/micro/f64_rate.hip): these kernels are bound by the instruction count of their longest wave,
+// so their loops are split by regime and carry no per-step tests.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
