@@ -601,6 +601,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = kVitThreads / 64;
+  static_assert(NW <= 16, "the per-wave partials are combined inside one DPP row");
   const ClipDesc cd = clips[clip];
   if (ci.status == AFX_CLIP_NONFINITE || ci.T < 1) {
     if (tid == 0) { st[0] = 0.0; st[1] = 0.0; st[2] = 1.0; st[3] = 0.0; }
@@ -630,7 +631,23 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   // (max value, lowest index) over the wave of a per-lane (value, index): DPP butterflies, no LDS round trips
   auto wave_best = [&](double& bv, int& bi) {
     const double m = wave_max_dpp(bv);
-    bi = wave_min_dpp(bv == m ? bi : (1 << 30));
+    const unsigned long long at = __ballot(bv == m);                       // lanes that hold the maximum (never none)
+    if (__popcll(at) == 1) bi = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(at));   // the usual case: one holder
+    else bi = wave_min_dpp(bv == m ? bi : (1 << 30));                     // a tie: the lowest state index among them
+    bv = m;
+  };
+  // the same over the first 16 lanes only (the per-wave partials): one DPP row, one readlane
+  auto row0_best = [&](double& bv, int& bi) {
+    double v = bv;
+    v = fmax(v, dpp_dd<0xB1>(v)); v = fmax(v, dpp_dd<0x4E>(v)); v = fmax(v, dpp_dd<0x141>(v)); v = fmax(v, dpp_dd<0x140>(v));
+    const double m = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
+    const unsigned long long at = __ballot(bv == m) & 0xffffull;
+    if (__popcll(at) == 1) bi = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(at));
+    else {
+      int x = bv == m ? bi : (1 << 30);
+      x = min(x, F0_DPP_I(x, 0xB1)); x = min(x, F0_DPP_I(x, 0x4E)); x = min(x, F0_DPP_I(x, 0x141)); x = min(x, F0_DPP_I(x, 0x140));
+      bi = __builtin_amdgcn_readlane(x, 0);
+    }
     bv = m;
   };
   // The block-wide (max, first arg-max) of a column is assembled from per-wave partials that the producing step
@@ -642,7 +659,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   auto get_best = [&](int set, double& gmax, int& garg) {
     double bv = -INFINITY; int bi = 1 << 30;
     if (lane < NW) { bv = redv[set * 16 + lane]; bi = redi[set * 16 + lane]; }
-    wave_best(bv, bi);
+    row0_best(bv, bi);
     gmax = bv; garg = bi;
   };
 
@@ -710,8 +727,9 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
     stamp(0);
     double* const vout = vclip + (size_t)t * S;
     double pbv = -INFINITY; int pbi = 1 << 30;          // this thread's (max, lowest index) of the new column
-    auto note = [&](double xv, double xu, int jb) {
-      if (xv > pbv || (xv == pbv && jb < pbi)) { pbv = xv; pbi = jb; }
+    auto note = [&](double xv, double xu, int jb, bool first) {
+      if (first) { pbv = xv; pbi = jb; }                                 // a thread's first target: nothing to compare with
+      else if (xv > pbv || (xv == pbv && jb < pbi)) { pbv = xv; pbi = jb; }
       if (xu > pbv || (xu == pbv && nb + jb < pbi)) { pbv = xu; pbi = nb + jb; }
     };
     double gmax = 0.0; int garg = 0;
@@ -780,7 +798,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
       if (live) {
         put_value(vcur, jb, xv, xu);
         vout[jb] = xv; vout[nb + jb] = xu;
-        note(xv, xu, jb);
+        note(xv, xu, jb, base == 0);
       }
     }
     stamp(3);
