@@ -266,6 +266,19 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
   __syncthreads();
 
   const bool shared_chunks = W == 2 * hop;
+  // AFX_F0_DEBUG & 32: cycles per phase of workgroup (0, 0), printed per wave (developer aid)
+  const bool stamping = (fp.debug & 32) != 0;
+  unsigned long long ph[8] = {}, ph_t = 0;
+  auto stamp = [&](int i) {
+    if (stamping) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i >= 0) ph[i] += now - ph_t;
+      ph_t = now;
+    }
+  };
   double carry[RR];
 #pragma unroll
   for (int r = 0; r < RR; ++r) carry[r] = 0.0;
@@ -276,6 +289,7 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
     const int64_t slot = cd.frame_base + t;
     const double* F = Y + (size_t)f * hop;
 
+    stamp(-1);
     // ---- autocorrelation acf[tau] = sum_{i=1..W} y[i] y[i + tau]  (what irfft(rfft(y) rfft(y[W:0:-1])) [W:] is).
     // With W = 2 hop a frame is two hop-sized chunks and neighbouring frames share one: the wave keeps the
     // previous chunk's partial sums and adds one new chunk per frame (5 chunks for its 4 frames instead of 8).
@@ -323,6 +337,7 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
     } else {
       chunk(F, (fp.debug & 4) ? 8 : W, acc);
     }
+    stamp(0);
     // ---- difference function d = (e[0] + e[tau]) [float32] - 2 acf [float64]
     const float* Erow = energy + slot * (int64_t)fp.n_tau_pad;
     const float e0 = Erow[0];
@@ -356,6 +371,7 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
       }
     }
     F0_WAVE_SYNC();
+    stamp(1);
     // ---- troughs (librosa.util.localmin, with the pyin rule for index 0), compacted in increasing lag:
     // at most every second lag is a trough, so the threshold loop below runs over CS = ceil(n_troughs / 64)
     // dense slots instead of one slot per 64 lags
@@ -380,6 +396,7 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
       }
     }
     F0_WAVE_SYNC();
+    stamp(2);
     int cnt = 0;
     double vp = 0.0;
     if (n_tr > 0) {
@@ -416,17 +433,27 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
           if (kk <= kF0Thresholds) kin[c] = kk;
         }
       }
-      auto next_event = [&](int after) {                                     // smallest kin > after (wave-uniform)
-        int m = 1 << 20;
+      // the entry events as two 64-bit masks over k (a flag per threshold in the wave's idle D row, one ballot per
+      // half): stepping from run to run is then scalar bit scanning, not a wave reduction
+      int* EV = reinterpret_cast<int*>(D);
+      EV[lane] = 0; EV[lane + 64] = 0;
+      F0_WAVE_SYNC();
 #pragma unroll
-        for (int c = 0; c < CSM; ++c)
-          if (c < CS && kin[c] > after) m = min(m, kin[c]);
-        return wave_min_dpp(m);
+      for (int c = 0; c < CSM; ++c)
+        if (c < CS && kin[c] <= kF0Thresholds) EV[kin[c]] = 1;
+      F0_WAVE_SYNC();
+      unsigned long long ev0 = __ballot(EV[lane] != 0), ev1 = __ballot(EV[lane + 64] != 0);
+      F0_WAVE_SYNC();
+      auto take_event = [&]() -> int {                                       // smallest remaining event, removed
+        int k = 1 << 20;
+        if (ev0) { k = (int)__builtin_ctzll(ev0); ev0 &= ev0 - 1; }
+        else if (ev1) { k = 64 + (int)__builtin_ctzll(ev1); ev1 &= ev1 - 1; }
+        return k;
       };
-      int ka = next_event(0);
+      int ka = take_event();
       while (ka <= kmax) {
-        int kb = next_event(ka);                                             // the run is ka .. kb - 1
-        if (kb > kmax + 1) kb = kmax + 1;
+        const int kn = take_event();                                         // the run is ka .. kn - 1
+        const int kb = kn > kmax + 1 ? kmax + 1 : kn;
         int pos[CSM];
         int n = 0;
 #pragma unroll
@@ -450,8 +477,9 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
           for (int c = 0; c < CSM; ++c)
             if (c < CS) pr[c] += fe[c] * bk;
         }
-        ka = kb;
+        ka = kn;
       }
+      stamp(3);
       // global minimum (first occurrence) collects the mass of the thresholds it does not undercut
       double hm = INFINITY;
 #pragma unroll
@@ -472,6 +500,7 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
 #pragma unroll
       for (int c = 0; c < CSM; ++c)
         if (tr[c] && lane + 64 * c == jm) pr[c] += extra;
+      stamp(4);
       // ---- candidates in increasing period: refine, map to a pitch bin
 #pragma unroll
       for (int c = 0; c < CSM; ++c) {
@@ -499,21 +528,34 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
         }
       }
       F0_WAVE_SYNC();
+      stamp(5);
       // several candidates in one bin: the last (longest period) wins, as numpy's indexed assignment
-      for (int j = lane; j < cnt; j += 64) {
-        const int b = CB[j];
-        const bool keep = (j == cnt - 1) || CB[j + 1] != b;
-        cand_bin[slot * fp.cap + j] = (int16_t)(keep ? b : -1);
-        cand_prob[slot * fp.cap + j] = CP[j];
-        if (!keep) CB[j] = -1;
+      double val[CSM];                     // this lane's kept in-range candidates (0 otherwise), j = lane + 64 m
+#pragma unroll
+      for (int m = 0; m < CSM; ++m) {
+        val[m] = 0.0;
+        const int j = lane + 64 * m;
+        if (j < cnt) {
+          const int b = CB[j];
+          const bool keep = (j == cnt - 1) || CB[j + 1] != b;
+          const double pj = CP[j];
+          cand_bin[slot * fp.cap + j] = (int16_t)(keep ? b : -1);
+          cand_prob[slot * fp.cap + j] = pj;
+          if (keep && b >= 0 && b < fp.n_bins) val[m] = pj;
+        }
       }
-      F0_WAVE_SYNC();
       // voiced_prob = np.sum(observation[:n_bins], axis=0): numpy adds the rows one after another, i.e. the kept
       // candidates in ascending bin order (descending j), sequentially.  The order is reproduced because the sum is
       // mathematically 1 for a strongly voiced frame and the unvoiced observation is (1 - sum) / n_bins: 0 or 1e-19.
-      for (int j = cnt - 1; j >= 0; --j) {
-        const int b = CB[j];
-        if (b >= 0 && b < fp.n_bins) vp += CP[j];
+      // The terms come out of the lanes' registers by readlane (a dropped candidate adds an exact +0.0): a loop over
+      // LDS cost two dependent round trips per term.
+#pragma unroll
+      for (int m = CSM - 1; m >= 0; --m) {
+        const int lo = 64 * m;
+        const int hi = (cnt < lo + 64 ? cnt : lo + 64) - 1;
+        const int vlo = __double2loint(val[m]), vhi = __double2hiint(val[m]);
+        for (int j = hi; j >= lo; --j)
+          vp += __hiloint2double(__builtin_amdgcn_readlane(vhi, j - lo), __builtin_amdgcn_readlane(vlo, j - lo));
       }
       F0_WAVE_SYNC();
     }
@@ -521,7 +563,11 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
       cand_cnt[slot] = cnt;
       cand_vp[slot] = vp < 0.0 ? 0.0 : (vp > 1.0 ? 1.0 : vp);
     }
+    stamp(6);
   }
+  if (stamping && blockIdx.x == 1 && blockIdx.y == 0 && lane == 0)
+    printf("yin wave %d: acf %llu diff+cmean %llu troughs %llu thresholds %llu minimum %llu candidates %llu write+vp %llu\n", wave,
+           ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
 }
 
 // ---------------------------------------------------------------------------------------------
