@@ -13,7 +13,7 @@
 //                 transition matrix -- value-only forward pass, one barrier per step, the arg-max
 //                 recomputed along the path while back-tracking -- and the f0 statistics
 //                 (feature_extractor.py:97-114)
-// A wave issues one instruction per ~9 cycles on this part and two waves per SIMD one per ~4.6
+// A wave issues one instruction per ~9 ticks on this part however many waves share its SIMD
 // (tools/micro/f64_rate.hip): these kernels are bound by the instruction count of their longest wave,
 // so their loops are split by regime and carry no per-step tests.
 #include <hip/hip_runtime.h>

@@ -43,7 +43,7 @@ template <int OP> void run(const char* name, int waves) {
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  unsigned long long h[256 * 16]; hipMemcpy(h, d, blocks * waves * 8, hipMemcpyDeviceToHost);
+  static unsigned long long h[256 * 16]; hipMemcpy(h, d, blocks * waves * 8, hipMemcpyDeviceToHost);
   double sum = 0; for (int i = 0; i < blocks * waves; ++i) sum += h[i];
   const double n = iters * 8.0;
   // s_memtime counts at 100 MHz on this part: also report wall-clock ns per instruction per SIMD
@@ -57,5 +57,8 @@ int main() {
                   run<3>("v_cmp_gt_f64", 4); run<5>("v_mul_f64", 4); run<6>("v_cndmask_b32", 4); }
     else { run<4>("v_add_f32", 8); run<0>("v_add_f64", 8); run<1>("v_max_f64", 8); run<2>("v_fma_f64", 8); run<3>("v_cmp_gt_f64", 8); }
   }
+  // more waves per SIMD: a wave64 VALU instruction occupies the SIMD for four cycles, so once the SIMD saturates the
+  // ticks per instruction per wave are 4 x (waves per SIMD) -- which also calibrates the tick against the cycle
+  run<4>("v_add_f32", 12); run<4>("v_add_f32", 16); run<0>("v_add_f64", 12); run<0>("v_add_f64", 16);
   return 0;
 }
