@@ -14,6 +14,7 @@
 
 #include "afx_device.h"
 #include "afx_f0.h"
+#include "afx_frames3.h"
 #include "afx_internal.h"
 
 namespace afx {
@@ -42,6 +43,8 @@ struct afx_plan {
   KParams kp{};
   HostTables ht;
   DevTables dt{};
+  F3Tables f3{};              // k_frames3 (n_fft 1024 / hop 256): mel schedule + twiddle source
+  bool use_f3 = false;
   std::vector<void*> table_allocs;
   DevBuf samples, clips, info, blocks, bsum, logmel, rms, mfcc, stats, frames, frame_offs, stamps;
   // extract_f0 (pYIN): tables for the last (fmin, fmax) used and the stage's workspace
@@ -228,7 +231,20 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
   pl->dt.mel_n_slots = t.mel.n_slots;
   pl->dt.mel_ntaps = t.taps.usable ? (int32_t)t.taps.taps.size() : 0;
   pl->dt.n_groups = t.mel.n_groups;
-  kp.rms_sub = frames2_eligible(kp, pl->dt) ? kp.trim_hop / kp.hop : 0;
+  if (t.f3mel.usable) {
+    if ((rc = upload(pl, t.f3mel.w.data(), t.f3mel.w.size(), &pl->f3.mel_w)) != AFX_OK ||
+        (rc = upload(pl, t.f3mel.meta.data(), t.f3mel.meta.size(), &pl->f3.mel_meta)) != AFX_OK) {
+      afx_plan_destroy(pl);
+      return rc;
+    }
+    pl->f3.window = pl->dt.window; pl->f3.w1024 = pl->dt.post;
+    pl->f3.mel_rounds = t.f3mel.rounds; pl->f3.mel_wfloats = (int32_t)t.f3mel.w.size();
+    for (int r = 0; r < kF3MaxRounds; ++r) {
+      pl->f3.mel_nb[r] = t.f3mel.nb[r]; pl->f3.mel_width[r] = t.f3mel.width[r]; pl->f3.mel_woff[r] = t.f3mel.woff[r];
+    }
+  }
+  pl->use_f3 = frames3_eligible(kp, pl->f3);
+  kp.rms_sub = (pl->use_f3 || frames2_eligible(kp, pl->dt)) ? kp.trim_hop / kp.hop : 0;
   pl->dt.n_cgroups = t.dctb.n_cgroups;
   if (t.dctb.P.size() < 64) pl->dt.dctP = nullptr;
   hipDeviceProp_t prop;
@@ -379,8 +395,13 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
       d_stamps = (unsigned long long*)pl->stamps.p;
       HIP_TRY(hipMemsetAsync(d_stamps, 0, (size_t)grid * kWaves * kStampPhases * 8, s));
     }
-    TIMED(AFX_K_FRAMES, launch_frames(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks,
-                                      pl->dt, kp, (float*)pl->logmel.p, (float*)pl->rms.p, grid, d_stamps));
+    const bool f3 = pl->use_f3 && !want_stamps && !(kp.flags & 0x7f00);
+    if (f3)
+      TIMED(AFX_K_FRAMES, launch_frames3(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks, pl->f3, kp,
+                                         (float*)pl->logmel.p, pl->n_cu));
+    else
+      TIMED(AFX_K_FRAMES, launch_frames(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks,
+                                        pl->dt, kp, (float*)pl->logmel.p, (float*)pl->rms.p, grid, d_stamps));
     if (want_stamps) {
       std::vector<unsigned long long> h((size_t)grid * kWaves * kStampPhases);
       HIP_TRY(hipMemcpyAsync(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost, s));
@@ -404,7 +425,7 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
         fprintf(stderr, "\n");
       }
     }
-    TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax));
+    TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax, f3));
   }
   TIMED(AFX_K_STATS, launch_stats(s, d_clips, d_info, kp, (const float*)pl->mfcc.p, (const float*)pl->rms.p,
                                   (float*)pl->stats.p, d_frames, (const int64_t*)pl->frame_offs.p, n));

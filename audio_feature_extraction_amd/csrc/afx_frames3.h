@@ -1,0 +1,51 @@
+// k_frames3 (afx_frames3.hip): tables, LDS geometry and launcher.  Internal to libafx.so.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "afx_device.h"
+
+namespace afx {
+
+constexpr int kF3ExFloats = 2176;          // per-wave LDS image: 64 rows x 17 float2 (exchange 1, padded) = 8704 B
+constexpr int kF3TabFloats = 2048;         // pass-2 twiddles 128 float2 + two last-pass tables of 7 x 64 float2
+constexpr int kF3MaxRounds = 8;            // mel schedule rounds
+constexpr int kF3MaxBatches = 8;           // batches of 4 taps per lane and round
+
+// Mel schedule of k_frames3.  One frame pair at a time, a lane accumulates `4 * nb` consecutive taps of one
+// filter; `width` adjacent lanes share a filter (contiguous tap chunks) and are summed by DPP.  Rounds are
+// chosen by build_f3_mel (afx_tables.cpp) so that the padded tap count over all rounds is small.
+struct HostF3Mel {
+  int32_t rounds = 0;
+  int32_t nb[kF3MaxRounds] = {};           // batches per lane
+  int32_t width[kF3MaxRounds] = {};        // lanes per filter: 1, 2, 4, 8
+  int32_t woff[kF3MaxRounds] = {};         // float offset of the round's weights
+  std::vector<float> w;                    // [round][batch][lane][4]
+  std::vector<int32_t> meta;               // [round][lane]: first bin | filter << 11 | owner << 20
+  bool usable = false;
+};
+
+struct F3Tables {
+  const float* window;      // n_fft floats
+  const float* w1024;       // exp(-2 pi i k / 1024), k < 512, as float2
+  const float* mel_w;
+  const int32_t* mel_meta;
+  int32_t mel_rounds;
+  int32_t mel_wfloats;
+  int32_t mel_nb[kF3MaxRounds];
+  int32_t mel_width[kF3MaxRounds];
+  int32_t mel_woff[kF3MaxRounds];
+};
+
+// mel_dense: n_mels x n_bins (librosa float32 values); max_slot: highest float2 slot of the image a padded tap may read
+void build_f3_mel(const std::vector<float>& mel_dense, int n_mels, int n_bins, int max_slot, HostF3Mel& out);
+
+size_t frames3_lds_bytes(int waves, const F3Tables& ft);
+bool frames3_eligible(const KParams& kp, const F3Tables& ft);
+int frames3_waves(const F3Tables& ft);
+hipError_t launch_frames3(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
+                          const F3Tables& ft, const KParams& kp, float* logmel, int n_cu);
+
+}  // namespace afx

@@ -1,0 +1,417 @@
+// k_frames3: the wave-autonomous frame kernel of libafx.so (gfx950) for n_fft = 1024 / hop = 256
+// (reference call sites: audio_feature_extraction_toolkit/core/feature_extractor.py:127-134 -> librosa stft,
+// |.|^2, filters.mel, power_to_db; the framing, window and mel semantics are those of oracle/cpu_ref.py).
+//
+// Why a third frame kernel.  tools/micro/valu_rate.hip measured on MI355X that ONE wave issues a vector
+// instruction every ~8 cycles whatever the instruction, and that a SIMD only approaches its packed-f32 rate with
+// four waves resident (4.7 / 3.7 / 3.3 cycles per v_pk_fma_f32 at 2 / 3 / 4 waves).  k_frames2 runs two waves per
+// SIMD (204 VGPRs, 78 KB of LDS per 4-wave workgroup, two workgroup barriers per 16 frames) and was measured at
+// ~86 % of that two-wave issue limit: it cannot get faster without more waves or fewer instructions.  This kernel
+// does both:
+//   * every wave is autonomous -- it owns a 16-frame block, walks it as 8 frame pairs, and never meets a
+//     workgroup barrier after the table set-up.  Per wave the LDS holds one 8.5 KB image that serves, in turn, the
+//     two FFT exchanges, the pair's power spectrum and the edge-row staging; 12 or 16 waves share one set of
+//     twiddle / mel tables (one workgroup per CU);
+//   * the butterflies are written as packed-f32 instructions with VOP3P op_sel / neg modifiers (inline asm): a
+//     multiplication by +-i or the swap a complex product needs is a source modifier, not a v_mov pair -- the
+//     compiler's own packing of k_frames2 spent 14 % of its instructions on such moves;
+//   * sample rows (lane l holds samples l + 64 u) are loaded straight from global memory as dwords, one row per
+//     instruction, together with their left neighbours (pre-emphasis), 8 new rows per pair; nothing is re-cut
+//     through LDS;
+//   * mel: per pair, lanes map to filters through a host-built schedule of "rounds" (width 1, 2, 4 or 8 lanes per
+//     filter, afx_tables.cpp: build_f3_mel) -- packed FMAs on (frame A, frame B), quad / half-row DPP reductions;
+//   * the log-mel spill is frame-major ([frame][mel], 512 B per frame at 128 mels) so that a pair's values leave
+//     as whole 512-byte rows; k_dct16<.., true> reads that layout.
+//
+// FFT schedule (unchanged mathematics from k_frames2): z = w*yA + i*w*yB, 1024 points as 16 x 8 x 8,
+//   pass 1  radix 16 over u (lane l holds points l + 64 u)                 -> Y[l][k1]
+//   xchg 1  image [l][17] (one pad slot per row: base + immediate on both sides), lane reads l_src = (l>>4) + 4u, k1 = l & 15
+//   pass 2  two radix-8 butterflies (a = (l>>4) + 4i, over r: l_src = a + 8r), twiddle W_128^(k1 r)
+//   xchg 2  image [a][128] at j = k1 + 16 k2, plain layout (both sides conflict-free)
+//   pass 3  radix 8 over a for butterflies ja = l and jb = 128 - l (lane 0: 0 and 64), twiddle W_1024^(a j):
+//           the lane then owns Z[k] and Z[N-k], so X_A, X_B follow with adds only.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "afx_device.h"
+#include "afx_frames3.h"
+
+namespace afx {
+
+typedef float v2 __attribute__((ext_vector_type(2)));
+
+// ---- packed-f32 helpers (VOP3P source modifiers do the swaps and sign flips) ------------------------------------
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ v2 add_mi(v2 a, v2 b) {
+  v2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ v2 add_pi(v2 a, v2 b) {
+  v2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+// complex product v * w
+__device__ __forceinline__ v2 cmul(v2 v, v2 w) {
+  v2 t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(v), "v"(w));                       // (v.x w.x, v.y w.x)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(v), "v"(w), "v"(t));
+  return d;
+}
+// the same with the (constant) twiddle in scalar registers
+__device__ __forceinline__ v2 cmul_s(v2 v, v2 w) {
+  v2 t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(v), "s"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(v), "s"(w), "v"(t));
+  return d;
+}
+// b + (-i) h e  and  b + i h e   (h = H.x)
+__device__ __forceinline__ v2 fma_mi(v2 e, v2 H, v2 b) {
+  v2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(e), "s"(H), "v"(b)); return d;
+}
+__device__ __forceinline__ v2 fma_pi(v2 e, v2 H, v2 b) {
+  v2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(e), "s"(H), "v"(b)); return d;
+}
+// (s.x^2 + d.y^2, s.y^2 + d.x^2)
+__device__ __forceinline__ v2 sqsum(v2 s, v2 d) {
+  v2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %1" : "=v"(t) : "v"(s));
+  asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[1,1,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(d), "v"(t));
+  return r;
+}
+
+__device__ __forceinline__ void f3_dft4(v2& x0, v2& x1, v2& x2, v2& x3) {
+  const v2 a = x0 + x2, b = x0 - x2, c = x1 + x3, e = x1 - x3;
+  x0 = a + c; x2 = a - c; x1 = add_mi(b, e); x3 = add_pi(b, e);
+}
+
+// radix-8 butterfly, natural order in and out (inputs already twiddled)
+__device__ __forceinline__ void f3_dft8(v2* x, const v2 H) {
+  v2 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+  v2 o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7];
+  f3_dft4(e0, e1, e2, e3);
+  f3_dft4(o0, o1, o2, o3);
+  const v2 q1 = add_mi(o1, o1);          // o1 * W8^1 = h q1
+  const v2 q3 = add_pi(o3, o3);          // o3 * W8^3 = -h q3
+  x[0] = e0 + o0; x[4] = e0 - o0;
+  x[1] = q1 * H + e1; x[5] = e1 - q1 * H;
+  x[2] = add_mi(e2, o2); x[6] = add_pi(e2, o2);
+  x[3] = e3 - q3 * H; x[7] = q3 * H + e3;
+}
+
+// radix-16 butterfly as 4 x 4, W16 twiddles folded into the second layer's adds where they are h (1 -+ i) or -i
+__device__ __forceinline__ void f3_dft16(v2* x, const v2 H, const v2 W1, const v2 W3) {
+  v2 t0[4], t1[4], t2[4], t3[4];
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) {
+    v2 a = x[n2], b = x[n2 + 4], c = x[n2 + 8], d = x[n2 + 12];
+    f3_dft4(a, b, c, d);
+    t0[n2] = a; t1[n2] = b; t2[n2] = c; t3[n2] = d;
+  }
+  {   // k1 = 0
+    f3_dft4(t0[0], t0[1], t0[2], t0[3]);
+    x[0] = t0[0]; x[4] = t0[1]; x[8] = t0[2]; x[12] = t0[3];
+  }
+  {   // k1 = 1: twiddles W16^1, W16^2 = h (1 - i), W16^3
+    const v2 p1 = cmul_s(t1[1], W1), p3 = cmul_s(t1[3], W3), q = add_mi(t1[2], t1[2]);
+    const v2 a = q * H + t1[0], b = t1[0] - q * H, c = p1 + p3, e = p1 - p3;
+    x[1] = a + c; x[9] = a - c; x[5] = add_mi(b, e); x[13] = add_pi(b, e);
+  }
+  {   // k1 = 2: twiddles W16^2, W16^4 = -i, W16^6 = -h (1 + i)
+    const v2 q1 = add_mi(t2[1], t2[1]), q3 = add_pi(t2[3], t2[3]);
+    const v2 a = add_mi(t2[0], t2[2]), b = add_pi(t2[0], t2[2]);
+    const v2 c = q1 - q3, e = q1 + q3;                       // both still to be scaled by h
+    x[2] = c * H + a; x[10] = a - c * H; x[6] = fma_mi(e, H, b); x[14] = fma_pi(e, H, b);
+  }
+  {   // k1 = 3: twiddles W16^3, W16^6, W16^9 = -W16^1
+    const v2 p1 = cmul_s(t3[1], W3), m3 = cmul_s(t3[3], W1), q = add_pi(t3[2], t3[2]);
+    const v2 a = t3[0] - q * H, b = q * H + t3[0], c = p1 - m3, e = p1 + m3;
+    x[3] = a + c; x[11] = a - c; x[7] = add_mi(b, e); x[15] = add_pi(b, e);
+  }
+}
+
+__device__ __forceinline__ float f3_pre1(float y, float prev, float b1) {     // as scipy.signal.lfilter rounds it
+#pragma clang fp contract(off)
+  const float p = b1 * prev;
+  return y + p;
+}
+__device__ __forceinline__ float f3_pre0(float y0, float y1) {                // librosa's zi = 2 y0 - y1
+#pragma clang fp contract(off)
+  const float t = 2.0f * y0;
+  const float zi = t - y1;
+  return zi + y0;
+}
+__device__ __forceinline__ uint32_t f3_ord(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+#define F3_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, false))
+
+size_t frames3_lds_bytes(int waves, const F3Tables& ft) {
+  return (size_t)(waves * kF3ExFloats + kF3TabFloats + ft.mel_wfloats + ft.mel_rounds * 64) * sizeof(float);
+}
+
+template <int FMT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__ samples,
+                                                        ClipInfo* __restrict__ info,
+                                                        const BlockDesc* __restrict__ blocks, int nblocks,
+                                                        F3Tables ft, KParams kp,
+                                                        float* __restrict__ logmel) {
+  constexpr int N = 1024, HOP = 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const tabs = smem + WAVES * kF3ExFloats;
+  v2* const T2 = reinterpret_cast<v2*>(tabs);                 // [r][16]: W_128^(c r)
+  v2* const T3a = reinterpret_cast<v2*>(tabs + 256);          // [r-1][lane]: W_1024^(ja r)
+  v2* const T3b = reinterpret_cast<v2*>(tabs + 256 + 896);    // [r-1][lane]: W_1024^(jb r)
+  float* const MW = tabs + kF3TabFloats;                      // mel weights [round][batch][lane][4]
+  int* const MM = reinterpret_cast<int*>(MW + ft.mel_wfloats);   // mel meta [round][lane]
+  v2* const E = reinterpret_cast<v2*>(smem + wave * kF3ExFloats);
+  float* const XB = reinterpret_cast<float*>(E);
+
+  // ---- once per workgroup: tables -> LDS, the wave's image zeroed (padded mel taps read whatever lies there)
+  {
+    const v2* w1024 = reinterpret_cast<const v2*>(ft.w1024);
+    auto W = [&](int m) { const v2 v = w1024[m & 511]; return (m & 512) ? -v : v; };
+    if (tid < 128) T2[tid] = W(8 * (tid >> 4) * (tid & 15));
+    if (tid < 64) {
+      const int jbt = tid ? 128 - tid : 64;
+#pragma unroll
+      for (int r = 1; r < 8; ++r) { T3a[(r - 1) * 64 + tid] = W(tid * r); T3b[(r - 1) * 64 + tid] = W(jbt * r); }
+    }
+    for (int i = tid; i < ft.mel_wfloats; i += WAVES * 64) MW[i] = ft.mel_w[i];
+    for (int i = tid; i < ft.mel_rounds * 64; i += WAVES * 64) MM[i] = ft.mel_meta[i];
+    for (int i = lane; i < kF3ExFloats; i += 64) XB[i] = 0.f;
+  }
+  float wreg[16];                          // the lane's window values (w[n] = w[N - n]) x 0.5
+#pragma unroll
+  for (int u = 0; u < 16; ++u) wreg[u] = 0.5f * ft.window[u < 8 ? lane + 64 * u : (64 - lane) + 64 * (15 - u)];
+  __syncthreads();
+
+  const v2 H = {0.70710678118654752440f, 0.70710678118654752440f};
+  const v2 W1 = {0.92387953251128675613f, -0.38268343236508977173f};      // W16^1
+  const v2 W3 = {0.38268343236508977173f, -0.92387953251128675613f};      // W16^3
+  const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
+  const float b1 = kp.preemph_b1;
+  const int M = kp.n_mels;
+  const int jb = lane ? 128 - lane : 64;
+  // image slots (float2 units)
+  v2* const e1w = E + 17 * lane;
+  const v2* const e1r = E + 17 * (lane >> 4) + (lane & 15);
+  v2* const e2w = E + 128 * (lane >> 4) + (lane & 15);
+  v2* const ea = E + lane;                 // pass-3 reads of butterfly ja; power-spectrum bins lane + 128 s
+  v2* const eb = E + jb;                   // butterfly jb; bins jb + 384 - 128 (s - 4)
+
+  auto raw_ld = [&](int64_t idx) -> float {
+    if constexpr (FMT == AFX_FMT_S16) return (float)((const int16_t*)samples)[idx] * (1.0f / 32768.0f);
+    else return ((const float*)samples)[idx];
+  };
+
+  const int total_waves = gridDim.x * WAVES;
+  for (int b = blockIdx.x * WAVES + wave; b < nblocks; b += total_waves) {
+    const BlockDesc bd = blocks[b];
+    if (!bd.active) continue;
+    const int Tleft = bd.T - bd.t0;                       // frames left from this block on (>= 1)
+    const int npairs = Tleft >= 16 ? 8 : (Tleft + 1) >> 1;
+    const int64_t sbase = bd.sample_base;
+    auto interior = [&](int j0, int j1) -> bool {         // every sample of [j0, j1) and its predecessor exists and is kept
+      return (j0 - 1 >= bd.have_lo) && (j1 <= bd.have_hi) && (j0 >= bd.keep_lo) && (j1 <= bd.keep_hi);
+    };
+    auto edge_sample = [&](int j) -> float {              // pre-emphasised, trim-masked sample j (clamped loads)
+      const int lo = bd.have_lo, hi = bd.have_hi - 1;
+      const int jc = j < lo ? lo : (j > hi ? hi : j), jp = (j - 1) < lo ? lo : ((j - 1) > hi ? hi : (j - 1));
+      const float y = (jc == j) ? raw_ld(sbase + jc) : 0.f;
+      const float yp = (jp == j - 1) ? raw_ld(sbase + jp) : 0.f;
+      float v = y;
+      if (pre) {
+        v = f3_pre1(y, yp, b1);
+        if (j == lo) v = f3_pre0(raw_ld(bd.clip_off), raw_ld(bd.clip_off + 1));   // clip sample 0
+      }
+      return (j >= bd.keep_lo && j < bd.keep_hi) ? v : 0.f;
+    };
+
+    // ---- rows of the first pair: staged samples [0, 1280)
+    float rows[20];
+    if (interior(0, N + HOP)) {
+      float y[20], yp[20];
+#pragma unroll
+      for (int u = 0; u < 20; ++u) { y[u] = raw_ld(sbase + 64 * u + lane); yp[u] = raw_ld(sbase + 64 * u + lane - 1); }
+#pragma unroll
+      for (int u = 0; u < 20; ++u) rows[u] = pre ? f3_pre1(y[u], yp[u], b1) : y[u];
+    } else {
+#pragma unroll 1
+      for (int u = 0; u < 20; ++u) XB[64 * u + lane] = edge_sample(64 * u + lane);
+#pragma unroll
+      for (int u = 0; u < 20; ++u) rows[u] = XB[64 * u + lane];
+    }
+    float lmax = -INFINITY;
+    float* const tile = logmel + bd.frame_slot * (int64_t)M;     // [frame][mel]
+
+#pragma unroll 1
+    for (int p = 0; p < npairs; ++p) {
+      // ---- z = w yA + i w yB (frame A: rows 0..15, frame B: rows 4..19)
+      v2 z[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) z[u] = v2{wreg[u] * rows[u], wreg[u] * rows[u + 4]};
+      // the next pair shares rows 8..19 and brings 8 new ones: staged samples [512 (p+1) + 768, + 512)
+#pragma unroll
+      for (int u = 0; u < 12; ++u) rows[u] = rows[u + 8];
+      const bool more = p + 1 < npairs;
+      const int jn = 512 * (p + 1) + 768;
+      const bool nint = more && interior(jn, jn + 512);
+      float ny[8], nyp[8];
+      if (nint) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ny[u] = raw_ld(sbase + jn + 64 * u + lane); nyp[u] = raw_ld(sbase + jn + 64 * u + lane - 1); }
+      }
+
+      // ---- pass 1 + exchange 1
+      f3_dft16(z, H, W1, W3);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) e1w[k] = z[k];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) z[u] = e1r[68 * u];
+      // ---- pass 2 + exchange 2
+      {
+        v2 tw[8];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) tw[r] = T2[r * 16 + (lane & 15)];
+        v2 xa[8], xb[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { xa[r] = z[2 * r]; xb[r] = z[2 * r + 1]; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { xa[r] = cmul(xa[r], tw[r]); xb[r] = cmul(xb[r], tw[r]); }
+        f3_dft8(xa, H); f3_dft8(xb, H);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { e2w[16 * r] = xa[r]; e2w[16 * r + 512] = xb[r]; }
+      }
+      // ---- pass 3
+      v2 A[8], B[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { A[r] = ea[128 * r]; B[r] = eb[128 * r]; }
+#pragma unroll
+      for (int r = 1; r < 8; ++r) { A[r] = cmul(A[r], T3a[(r - 1) * 64 + lane]); B[r] = cmul(B[r], T3b[(r - 1) * 64 + lane]); }
+      f3_dft8(A, H); f3_dft8(B, H);
+      // A[s] = Z[lane + 128 s], B[s] = Z[jb + 128 s]; the mirror of A[s] is B[7-s].  Lane 0 owns the self-mirrored
+      // butterflies 0 and 64: its pairs are (A[s], A[8-s]) and (B[s], B[7-s]) -- re-seat its registers once so
+      // that the generic pairing below yields them (bins 128 s from A, 64 + 384 - 128 (s-4) from B).
+      v2 nyq = A[4];
+      if (lane == 0) { A[4] = B[4]; B[4] = A[5]; A[5] = B[5]; B[5] = A[6]; A[6] = B[6]; B[6] = A[7]; A[7] = B[7]; B[7] = A[0]; }
+      // ---- |X_A|^2, |X_B|^2 -> the image as PB[bin] = (A, B)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ea[128 * s] = sqsum(A[s] + B[7 - s], A[s] - B[7 - s]);
+#pragma unroll
+      for (int s = 4; s < 8; ++s) eb[384 - 128 * (s - 4)] = sqsum(A[s] + B[7 - s], A[s] - B[7 - s]);
+      if (lane == 0) E[512] = v2{4.f * nyq.x * nyq.x, 4.f * nyq.y * nyq.y};
+
+      // ---- mel + dB
+      const bool vA = 2 * p < Tleft, vB = 2 * p + 1 < Tleft;
+      float* const rowA = tile + (int64_t)(2 * p) * M;
+#pragma unroll 1
+      for (int rd = 0; rd < ft.mel_rounds; ++rd) {
+        const int meta = MM[rd * 64 + lane];
+        const v2* pp = E + (meta & 2047);
+        const float4* ww = reinterpret_cast<const float4*>(MW + ft.mel_woff[rd]) + lane;
+        v2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#define F3_BATCH(i)                                                                  \
+        {                                                                            \
+          const float4 c = ww[64 * (i)];                                             \
+          const v2 x0 = pp[4 * (i)], x1 = pp[4 * (i) + 1], x2 = pp[4 * (i) + 2], x3 = pp[4 * (i) + 3]; \
+          a0 = x0 * v2{c.x, c.x} + a0; a1 = x1 * v2{c.y, c.y} + a1;                 \
+          a0 = x2 * v2{c.z, c.z} + a0; a1 = x3 * v2{c.w, c.w} + a1;                 \
+        }
+        switch (ft.mel_nb[rd]) {
+          case 8: F3_BATCH(7)
+          case 7: F3_BATCH(6)
+          case 6: F3_BATCH(5)
+          case 5: F3_BATCH(4)
+          case 4: F3_BATCH(3)
+          case 3: F3_BATCH(2)
+          case 2: F3_BATCH(1)
+          default: F3_BATCH(0)
+        }
+#undef F3_BATCH
+        v2 acc = a0 + a1;
+        const int wd = ft.mel_width[rd];
+        if (wd >= 2) { acc.x += F3_DPP(acc.x, 0xB1); acc.y += F3_DPP(acc.y, 0xB1); }       // lane ^ 1
+        if (wd >= 4) { acc.x += F3_DPP(acc.x, 0x4E); acc.y += F3_DPP(acc.y, 0x4E); }       // lane ^ 2
+        if (wd >= 8) { acc.x += F3_DPP(acc.x, 0x141); acc.y += F3_DPP(acc.y, 0x141); }     // the other quad of 8
+        const float L0 = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc.x));
+        const float L1 = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc.y));
+        if (meta & (1 << 20)) {                               // this lane owns filter m
+          const int m = (meta >> 11) & 511;
+          rowA[m] = L0; rowA[M + m] = L1;
+          if (vA) lmax = fmaxf(lmax, L0);
+          if (vB) lmax = fmaxf(lmax, L1);
+        }
+      }
+
+      // ---- take in the next pair's 8 new rows
+      if (more) {
+        if (nint) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) rows[12 + u] = pre ? f3_pre1(ny[u], nyp[u], b1) : ny[u];
+        } else {
+#pragma unroll 1
+          for (int u = 0; u < 8; ++u) XB[64 * u + lane] = edge_sample(jn + 64 * u + lane);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) rows[12 + u] = XB[64 * u + lane];
+        }
+      }
+    }
+    // ---- clip maximum of the log-mel (power_to_db's top_db reference)
+    {
+      float v = lmax;
+      v = fmaxf(v, F3_DPP(v, 0xB1)); v = fmaxf(v, F3_DPP(v, 0x4E)); v = fmaxf(v, F3_DPP(v, 0x141)); v = fmaxf(v, F3_DPP(v, 0x140));
+      const int vi = __float_as_int(v);
+      const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+      const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+      const float mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+      if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx));
+    }
+  }
+}
+
+bool frames3_eligible(const KParams& kp, const F3Tables& ft) {
+  const int per = kp.hop > 0 ? kp.trim_hop / kp.hop : 0;
+  return kp.n_fft == 1024 && kp.hop == 256 && ft.mel_rounds > 0 && kp.n_mels <= 512 &&
+         kp.trim_hop % kp.hop == 0 && per >= 1 && per <= 4 && frames3_lds_bytes(12, ft) <= 160 * 1024 &&
+         !getenv("AFX_NO_FRAMES3");
+}
+
+int frames3_waves(const F3Tables& ft) {
+  static const int forced = getenv("AFX_F3_WAVES") ? atoi(getenv("AFX_F3_WAVES")) : 0;
+  if (forced == 12 || forced == 16) return frames3_lds_bytes(forced, ft) <= 160 * 1024 ? forced : 12;
+  return frames3_lds_bytes(16, ft) <= 160 * 1024 ? 16 : 12;
+}
+
+template <int FMT, int WAVES>
+static hipError_t launch_frames3_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
+                                   int nblocks, const F3Tables& ft, const KParams& kp, float* logmel, int n_cu) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3<FMT, WAVES>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  const int grid = std::min(n_cu, (nblocks + WAVES - 1) / WAVES);
+  hipLaunchKernelGGL((k_frames3<FMT, WAVES>), dim3(grid), dim3(WAVES * 64), frames3_lds_bytes(WAVES, ft), s, samples, info,
+                     blocks, nblocks, ft, kp, logmel);
+  return hipGetLastError();
+}
+
+hipError_t launch_frames3(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
+                          const F3Tables& ft, const KParams& kp, float* logmel, int n_cu) {
+  const int waves = frames3_waves(ft);
+  if (kp.fmt == AFX_FMT_S16)
+    return waves == 16 ? launch_frames3_t<AFX_FMT_S16, 16>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu)
+                       : launch_frames3_t<AFX_FMT_S16, 12>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
+  return waves == 16 ? launch_frames3_t<AFX_FMT_F32, 16>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu)
+                     : launch_frames3_t<AFX_FMT_F32, 12>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
+}
+
+}  // namespace afx

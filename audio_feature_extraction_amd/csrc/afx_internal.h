@@ -7,6 +7,7 @@
 
 #include "afx.h"
 #include "afx_consts.h"
+#include "afx_frames3.h"
 
 namespace afx {
 
@@ -56,6 +57,7 @@ struct HostTables {
   MelBlocks mel;
   MelTaps taps;
   DctBlocks dctb;
+  HostF3Mel f3mel;
 };
 
 // returns AFX_OK or a negative status; msg set on failure

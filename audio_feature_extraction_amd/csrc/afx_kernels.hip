@@ -1529,7 +1529,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
 // One wave per 16-frame log-mel tile: the tile's [mel][16 frames] layout is exactly the
 // MFMA B-operand order, so each k-step is one coalesced 256-byte load.
 // ---------------------------------------------------------------------------
-template <int NCG>
+template <int NCG, bool FM>
 __global__ __launch_bounds__(256) void k_dct(const ClipDesc* __restrict__ clips,
                                              const ClipInfo* __restrict__ info,
                                              const float* __restrict__ dctA, KParams kp,
@@ -1546,13 +1546,15 @@ __global__ __launch_bounds__(256) void k_dct(const ClipDesc* __restrict__ clips,
   const float theta = ord2f(ci.lmax_ord) - kp.top_db;
   const int f = lane & 15, q = lane >> 4;
   // tile layout [mel/4][frame][mel%4]: B[k = q][j = f] of k-step i is at 64 i + 4 f + q (one 256-B row per step)
-  const float* tile = logmel + (cd.frame_base + t0) * (int64_t)M + f * 4 + q;
+  // FM (k_frames3's spill): frame-major [frame][mel], B[k = q][j = f] of k-step i is mel 4 i + q of frame t0 + f
+  const float* tile = FM ? logmel + (cd.frame_base + t0 + f) * (int64_t)M + q
+                         : logmel + (cd.frame_base + t0) * (int64_t)M + f * 4 + q;
   f32x4 acc[NCG];
 #pragma unroll
   for (int c = 0; c < NCG; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
   for (int i = 0; i < NI; ++i) {
-    const float Lc = fmaxf(tile[i * 64], theta);
+    const float Lc = fmaxf(tile[FM ? i * 4 : i * 64], theta);
 #pragma unroll
     for (int c = 0; c < NCG; ++c)
       acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(dctA[((int64_t)c * NI + i) * 64 + lane], Lc, acc[c], 0, 0, 0);
@@ -1573,7 +1575,7 @@ __global__ __launch_bounds__(256) void k_dct(const ClipDesc* __restrict__ clips,
 // tiles; lane (f, q) fetches filters 16 s + 4 q + {0..3} of frame f with one 16-byte load (a wave-load is 1 KB
 // contiguous), all loads of its tiles issued before the first use; the DCT matrix sits in registers.
 constexpr int kDctTiles = 1;
-template <int NCG>
+template <int NCG, bool FM>
 __global__ __launch_bounds__(256) void k_dct16(const ClipDesc* __restrict__ clips,
                                                const ClipInfo* __restrict__ info,
                                                const float* __restrict__ dctP, KParams kp,
@@ -1594,10 +1596,12 @@ __global__ __launch_bounds__(256) void k_dct16(const ClipDesc* __restrict__ clip
   for (int j = 0; j < kDctTiles; ++j) {
     const int t0 = (tile0 + j) * 16;
     // tiles past the clip's last frame are not read (t0 is wave-uniform); [mel/4][frame][mel%4]: quad row 4 s + q
-    const float* tile = logmel + (cd.frame_base + t0) * (int64_t)M + (q * 16 + f) * 4;
+    // FM: frame-major [frame][mel] -- the same four filters 16 s + 4 q + {0..3} of frame f, 16 bytes at mel offset 16 s + 4 q
+    const float* tile = FM ? logmel + (cd.frame_base + t0 + f) * (int64_t)M + q * 4
+                           : logmel + (cd.frame_base + t0) * (int64_t)M + (q * 16 + f) * 4;
 #pragma unroll
     for (int s = 0; s < 8; ++s)
-      x[j][s] = (s < S && t0 < ci.T) ? *reinterpret_cast<const float4*>(tile + s * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[j][s] = (s < S && t0 < ci.T) ? *reinterpret_cast<const float4*>(tile + s * (FM ? 16 : 256)) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float a[NCG][8][4];
 #pragma unroll
@@ -1852,29 +1856,36 @@ hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
   }
 }
 
-hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
-                      const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax) {
+template <bool FM>
+static hipError_t launch_dct_t(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
+                               const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax) {
   if (tb.dctP && kp.n_mels % 16 == 0 && kp.n_mels <= 128 && kp.n_mfcc <= 48) {
     dim3 g16(((max_tmax + 15) / 16 + 4 * kDctTiles - 1) / (4 * kDctTiles), n_clips);
     const int ncg = (kp.n_mfcc + 15) / 16;
-    if (ncg == 1) hipLaunchKernelGGL(k_dct16<1>, g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
-    else if (ncg == 2) hipLaunchKernelGGL(k_dct16<2>, g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
-    else hipLaunchKernelGGL(k_dct16<3>, g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
+    if (ncg == 1) hipLaunchKernelGGL((k_dct16<1, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
+    else if (ncg == 2) hipLaunchKernelGGL((k_dct16<2, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
+    else hipLaunchKernelGGL((k_dct16<3, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
     return hipGetLastError();
   }
   dim3 grid(((max_tmax + 15) / 16 + 3) / 4, n_clips);
   switch (tb.n_cgroups) {
-    case 1: hipLaunchKernelGGL(k_dct<1>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 2: hipLaunchKernelGGL(k_dct<2>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 3: hipLaunchKernelGGL(k_dct<3>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 4: hipLaunchKernelGGL(k_dct<4>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 5: hipLaunchKernelGGL(k_dct<5>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 6: hipLaunchKernelGGL(k_dct<6>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 7: hipLaunchKernelGGL(k_dct<7>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 8: hipLaunchKernelGGL(k_dct<8>, grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 1: hipLaunchKernelGGL((k_dct<1, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 2: hipLaunchKernelGGL((k_dct<2, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 3: hipLaunchKernelGGL((k_dct<3, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 4: hipLaunchKernelGGL((k_dct<4, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 5: hipLaunchKernelGGL((k_dct<5, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 6: hipLaunchKernelGGL((k_dct<6, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 7: hipLaunchKernelGGL((k_dct<7, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 8: hipLaunchKernelGGL((k_dct<8, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+
+hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
+                      const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax, bool frame_major) {
+  return frame_major ? launch_dct_t<true>(s, clips, info, tb, kp, logmel, mfcc, n_clips, max_tmax)
+                     : launch_dct_t<false>(s, clips, info, tb, kp, logmel, mfcc, n_clips, max_tmax);
 }
 
 hipError_t launch_stats(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const KParams& kp,

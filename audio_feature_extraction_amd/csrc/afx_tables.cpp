@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "afx_internal.h"
+#include "afx_frames3.h"
 
 namespace afx {
 
@@ -191,6 +192,74 @@ static void build_mel_taps(const afx_params& p, const std::vector<float>& W, Mel
   if (t.taps.empty()) t.taps.push_back(0.f);
 }
 
+
+// k_frames3's mel schedule (afx_frames3.h).  Filters sorted by tap count are cut into rounds of 64 / width filters;
+// a dynamic programme picks the widths: a round costs its batches (4 reads + 1 weight read + 4 packed FMAs each)
+// plus a fixed finish (reduction, two logs, two stores).
+void build_f3_mel(const std::vector<float>& W, int M, int NB, int max_slot, HostF3Mel& out) {
+  out = HostF3Mel();
+  std::vector<int> first(M, 0), nnz(M, 0), order(M);
+  for (int m = 0; m < M; ++m) {
+    int f = -1, l = -1;
+    for (int k = 0; k < NB; ++k) if (W[(size_t)m * NB + k] != 0.f) { if (f < 0) f = k; l = k; }
+    if (f >= 0) { first[m] = f; nnz[m] = l - f + 1; }
+    order[m] = m;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nnz[a] < nnz[b]; });
+  const int INF = 1 << 28;
+  // dp[r][i]: cheapest way to place the first i filters (sorted) in r rounds
+  std::vector<std::vector<int>> dp(kF3MaxRounds + 1, std::vector<int>(M + 1, INF)), from_w = dp, from_i = dp;
+  dp[0][0] = 0;
+  auto batches = [&](int i, int j, int w) {            // filters [i, j) at width w
+    const int maxt = nnz[order[j - 1]];
+    const int per = (maxt + w - 1) / w;
+    return std::max(1, (per + 3) / 4);
+  };
+  for (int r = 0; r < kF3MaxRounds; ++r)
+    for (int i = 0; i < M; ++i) {
+      if (dp[r][i] >= INF) continue;
+      for (int w = 1; w <= 8; w *= 2) {
+        const int j = std::min(M, i + 64 / w);
+        const int nb = batches(i, j, w);
+        if (nb > kF3MaxBatches) continue;
+        const int lg = w == 1 ? 0 : (w == 2 ? 1 : (w == 4 ? 2 : 3));
+        const int c = dp[r][i] + 9 * nb + 16 + 4 * lg;
+        if (c < dp[r + 1][j]) { dp[r + 1][j] = c; from_w[r + 1][j] = w; from_i[r + 1][j] = i; }
+      }
+    }
+  int best_r = -1;
+  for (int r = 1; r <= kF3MaxRounds; ++r) if (dp[r][M] < INF && (best_r < 0 || dp[r][M] < dp[best_r][M])) best_r = r;
+  if (best_r < 0) return;
+  std::vector<int> cut_i(best_r), cut_w(best_r);
+  for (int r = best_r, j = M; r >= 1; --r) { cut_i[r - 1] = from_i[r][j]; cut_w[r - 1] = from_w[r][j]; j = from_i[r][j]; }
+  out.rounds = best_r;
+  out.meta.assign((size_t)best_r * 64, 0);
+  for (int r = 0; r < best_r; ++r) {
+    const int i0 = cut_i[r], i1 = r + 1 < best_r ? cut_i[r + 1] : M, w = cut_w[r];
+    const int nb = batches(i0, i1, w), S = 4 * nb;
+    out.nb[r] = nb; out.width[r] = w; out.woff[r] = (int32_t)out.w.size();
+    out.w.resize(out.w.size() + (size_t)nb * 64 * 4, 0.f);
+    float* wr = out.w.data() + out.woff[r];
+    for (int i = i0; i < i1; ++i) {
+      const int m = order[i];
+      for (int q = 0; q < w; ++q) {
+        const int lane = (i - i0) * w + q;
+        int bin0 = first[m] + q * S;
+        const bool live = nnz[m] > 0 && bin0 < first[m] + nnz[m];
+        if (!live) bin0 = 0;
+        if (bin0 + S - 1 > max_slot) return;          // a padded tap would leave the image: unusable
+        out.meta[(size_t)r * 64 + lane] = bin0 | (m << 11) | ((q == 0) ? (1 << 20) : 0);
+        for (int t = 0; t < S; ++t) {
+          const int k = bin0 + t;
+          const float v = (live && k < first[m] + nnz[m] && k < NB) ? W[(size_t)m * NB + k] : 0.f;
+          wr[((size_t)(t >> 2) * 64 + lane) * 4 + (t & 3)] = v;
+        }
+      }
+    }
+  }
+  out.usable = true;
+}
+
 static void build_dct_blocks(const afx_params& p, const std::vector<float>& D, DctBlocks& d) {
   const int M = p.n_mels, K = p.n_mfcc;
   const int C = (K + 15) / 16, NI = M / 4;
@@ -230,6 +299,7 @@ void build_host_tables(const afx_params& p, HostTables& t) {
   build_mel_dense(p, t.mel_dense, mel_f);
   build_mel_blocks(p, t.mel_dense, mel_f, t.mel);
   build_mel_taps(p, t.mel_dense, t.taps);
+  build_f3_mel(t.mel_dense, M, N / 2 + 1, kF3ExFloats / 2 - 1, t.f3mel);
   t.dct.resize((size_t)K * M);
   for (int k = 0; k < K; ++k) {
     const double s = k == 0 ? std::sqrt(1.0 / M) : std::sqrt(2.0 / M);
