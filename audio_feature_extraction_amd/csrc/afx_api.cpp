@@ -239,9 +239,8 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
     }
     pl->f3.window = pl->dt.window; pl->f3.w1024 = pl->dt.post;
     pl->f3.mel_rounds = t.f3mel.rounds; pl->f3.mel_wfloats = (int32_t)t.f3mel.w.size();
-    for (int r = 0; r < kF3MaxRounds; ++r) {
-      pl->f3.mel_nb[r] = t.f3mel.nb[r]; pl->f3.mel_width[r] = t.f3mel.width[r]; pl->f3.mel_woff[r] = t.f3mel.woff[r];
-    }
+    for (int r = 0; r < kF3MaxRounds; ++r)
+      pl->f3.mel_rp[r] = (uint32_t)t.f3mel.nb[r] | ((uint32_t)t.f3mel.width[r] << 4) | ((uint32_t)t.f3mel.woff[r] << 8);
   }
   pl->use_f3 = frames3_eligible(kp, pl->f3);
   kp.rms_sub = (pl->use_f3 || frames2_eligible(kp, pl->dt)) ? kp.trim_hop / kp.hop : 0;
@@ -395,7 +394,7 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
       d_stamps = (unsigned long long*)pl->stamps.p;
       HIP_TRY(hipMemsetAsync(d_stamps, 0, (size_t)grid * kWaves * kStampPhases * 8, s));
     }
-    const bool f3 = pl->use_f3 && !want_stamps && !(kp.flags & 0x7f00);
+    const bool f3 = pl->use_f3 && !want_stamps && (!(kp.flags & 0x7f00) || getenv("AFX_F3_DEBUG"));
     if (f3)
       TIMED(AFX_K_FRAMES, launch_frames3(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks, pl->f3, kp,
                                          (float*)pl->logmel.p, pl->n_cu));

@@ -11,7 +11,8 @@ namespace afx {
 
 constexpr int kF3ExFloats = 2176;          // per-wave LDS image: 64 rows x 17 float2 (exchange 1, padded) = 8704 B
 constexpr int kF3TabFloats = 2048;         // pass-2 twiddles 128 float2 + two last-pass tables of 7 x 64 float2
-constexpr int kF3MaxRounds = 8;            // mel schedule rounds
+constexpr int kF3MaxRounds = 8;            // mel schedule rounds (table capacity)
+constexpr int kF3KernelRounds = 4;         // rounds the kernel unrolls; build_f3_mel never plans more
 constexpr int kF3MaxBatches = 8;           // batches of 4 taps per lane and round
 
 // Mel schedule of k_frames3.  One frame pair at a time, a lane accumulates `4 * nb` consecutive taps of one
@@ -34,9 +35,7 @@ struct F3Tables {
   const int32_t* mel_meta;
   int32_t mel_rounds;
   int32_t mel_wfloats;
-  int32_t mel_nb[kF3MaxRounds];
-  int32_t mel_width[kF3MaxRounds];
-  int32_t mel_woff[kF3MaxRounds];
+  uint32_t mel_rp[kF3MaxRounds];   // per round: batches | width << 4 | weight offset (floats) << 8
 };
 
 // mel_dense: n_mels x n_bins (librosa float32 values); max_slot: highest float2 slot of the image a padded tap may read

@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "afx_device.h"
 #include "afx_frames3.h"
@@ -57,6 +58,16 @@ __device__ __forceinline__ v2 cmul(v2 v, v2 w) {
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(v), "v"(w), "v"(t));
   return d;
 }
+// two independent products, interleaved: the dependent multiply / fma of one product would otherwise sit back to
+// back, and the compiler pads an inline-asm VALU dependence with an s_nop
+__device__ __forceinline__ void cmul2(v2& a, v2 wa, v2& b, v2 wb) {
+  v2 ta, tb, da, db;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(ta) : "v"(a), "v"(wa));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(tb) : "v"(b), "v"(wb));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(da) : "v"(a), "v"(wa), "v"(ta));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(db) : "v"(b), "v"(wb), "v"(tb));
+  a = da; b = db;
+}
 // the same with the (constant) twiddle in scalar registers
 __device__ __forceinline__ v2 cmul_s(v2 v, v2 w) {
   v2 t, d;
@@ -78,6 +89,23 @@ __device__ __forceinline__ v2 sqsum(v2 s, v2 d) {
   asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[1,1,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(d), "v"(t));
   return r;
 }
+
+__device__ __forceinline__ void sqsum2(v2 s0, v2 d0, v2 s1, v2 d1, v2& r0, v2& r1) {
+  v2 t0, t1;
+  asm("v_pk_mul_f32 %0, %1, %1" : "=v"(t0) : "v"(s0));
+  asm("v_pk_mul_f32 %0, %1, %1" : "=v"(t1) : "v"(s1));
+  asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[1,1,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(d0), "v"(t0));
+  asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[1,1,0] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(d1), "v"(t1));
+}
+// fmaxf without the canonicalising v_max x, x pair hipcc puts in front of it (the operands here are never signalling NaNs)
+__device__ __forceinline__ float f3_max(float a, float b) {
+  float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+
+// LDS read that the load/store optimizer leaves alone: merged into ds_read2_b64 two 8-byte reads take 8 LDS
+// cycles instead of 2 + 2 (MI355X_MICROARCH.md, LDS table; SQ_LDS_IDX_ACTIVE confirmed it on this kernel)
+typedef const volatile v2 __attribute__((address_space(3))) * f3_lds_cv2;
+__device__ __forceinline__ v2 ldv(const v2* p) { return *(f3_lds_cv2)(p); }
 
 __device__ __forceinline__ void f3_dft4(v2& x0, v2& x1, v2& x2, v2& x3) {
   const v2 a = x0 + x2, b = x0 - x2, c = x1 + x3, e = x1 - x3;
@@ -144,13 +172,22 @@ __device__ __forceinline__ uint32_t f3_ord(float f) {
   const uint32_t u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// timing-only ablation switches (libafx built with -DAFX_F3_DEBUG, AFX_DEBUG_SKIP bits << 8 in kp.flags); results invalid
+#ifdef AFX_F3_DEBUG
+#define F3_SKIP(bit) ((kp.flags & (bit)) != 0)
+#else
+#define F3_SKIP(bit) false
+#endif
 #define F3_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, false))
 
 size_t frames3_lds_bytes(int waves, const F3Tables& ft) {
   return (size_t)(waves * kF3ExFloats + kF3TabFloats + ft.mel_wfloats + ft.mel_rounds * 64) * sizeof(float);
 }
 
-template <int FMT, int WAVES>
+// NB0, NB1 > 0: the mel schedule is known at compile time to be two rounds of width 1 with NB0 and NB1 batches (the
+// reference's 22050 Hz / 128 mels is 2 and 7): the tap walk is then straight-line code, every LDS read of a round in
+// flight before its first FMA.  NB0 = 0: any schedule, batches behind uniform branches.
+template <int FMT, int WAVES, int NB0, int NB1>
 __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__ samples,
                                                         ClipInfo* __restrict__ info,
                                                         const BlockDesc* __restrict__ blocks, int nblocks,
@@ -206,6 +243,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     if constexpr (FMT == AFX_FMT_S16) return (float)((const int16_t*)samples)[idx] * (1.0f / 32768.0f);
     else return ((const float*)samples)[idx];
   };
+  // row loads of interior pairs: wave-uniform base pointer + 32-bit lane offset (global_load ... s[base] offset:imm)
+  typedef typename std::conditional<FMT == AFX_FMT_S16, int16_t, float>::type sample_t;
+  auto row_ld = [&](const sample_t* base, unsigned idx) -> float {
+    if constexpr (FMT == AFX_FMT_S16) return (float)base[idx] * (1.0f / 32768.0f);
+    else return base[idx];
+  };
+  const int n_rounds = ft.mel_rounds;
+  const int meta0 = MM[lane], meta1 = MM[64 + lane];       // straight-line schedule: the lane's two filters
+  const float amin = kp.amin;
 
   const int total_waves = gridDim.x * WAVES;
   for (int b = blockIdx.x * WAVES + wave; b < nblocks; b += total_waves) {
@@ -214,6 +260,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     const int Tleft = bd.T - bd.t0;                       // frames left from this block on (>= 1)
     const int npairs = Tleft >= 16 ? 8 : (Tleft + 1) >> 1;
     const int64_t sbase = bd.sample_base;
+    const sample_t* const sp = (const sample_t*)samples + sbase;      // staged sample 0 (may lie before the clip: edge path)
     auto interior = [&](int j0, int j1) -> bool {         // every sample of [j0, j1) and its predecessor exists and is kept
       return (j0 - 1 >= bd.have_lo) && (j1 <= bd.have_hi) && (j0 >= bd.keep_lo) && (j1 <= bd.keep_hi);
     };
@@ -230,19 +277,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       return (j >= bd.keep_lo && j < bd.keep_hi) ? v : 0.f;
     };
 
-    // ---- rows of the first pair: staged samples [0, 1280)
-    float rows[20];
-    if (interior(0, N + HOP)) {
-      float y[20], yp[20];
+    // ---- rows of the first pair: staged samples [0, 1280).  Rows live as pairs R[u] = (row u, row u + 4): exactly the
+    // (frame A, frame B) operands of z[u], so the window multiply is one packed instruction per point.
+    v2 R[16];
+    {
+      float rows[20];
+      if (interior(0, N + HOP)) {
+        float y[20], yp[20];
 #pragma unroll
-      for (int u = 0; u < 20; ++u) { y[u] = raw_ld(sbase + 64 * u + lane); yp[u] = raw_ld(sbase + 64 * u + lane - 1); }
+        for (int u = 0; u < 20; ++u) { y[u] = row_ld(sp, 64 * u + lane); yp[u] = row_ld(sp - 1, 64 * u + lane); }
 #pragma unroll
-      for (int u = 0; u < 20; ++u) rows[u] = pre ? f3_pre1(y[u], yp[u], b1) : y[u];
-    } else {
+        for (int u = 0; u < 20; ++u) rows[u] = pre ? f3_pre1(y[u], yp[u], b1) : y[u];
+      } else {
 #pragma unroll 1
-      for (int u = 0; u < 20; ++u) XB[64 * u + lane] = edge_sample(64 * u + lane);
+        for (int u = 0; u < 20; ++u) XB[64 * u + lane] = edge_sample(64 * u + lane);
 #pragma unroll
-      for (int u = 0; u < 20; ++u) rows[u] = XB[64 * u + lane];
+        for (int u = 0; u < 20; ++u) rows[u] = XB[64 * u + lane];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) R[u] = v2{rows[u], rows[u + 4]};
     }
     float lmax = -INFINITY;
     float* const tile = logmel + bd.frame_slot * (int64_t)M;     // [frame][mel]
@@ -252,45 +305,55 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       // ---- z = w yA + i w yB (frame A: rows 0..15, frame B: rows 4..19)
       v2 z[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) z[u] = v2{wreg[u] * rows[u], wreg[u] * rows[u + 4]};
-      // the next pair shares rows 8..19 and brings 8 new ones: staged samples [512 (p+1) + 768, + 512)
+      for (int u = 0; u < 16; ++u) z[u] = R[u] * v2{wreg[u], wreg[u]};
+      // the next pair shares rows 8..19 and brings 8 new ones, n[0..7] = rows 20..27 of this pair's window:
+      //   R'[u] = R[u + 8] (u < 8),  R'[8 + i] = (R[12 + i].y, n[i]),  R'[12 + i] = (n[i], n[4 + i])
 #pragma unroll
-      for (int u = 0; u < 12; ++u) rows[u] = rows[u + 8];
+      for (int u = 0; u < 8; ++u) R[u] = R[u + 8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) R[8 + i].x = R[12 + i].y;
       const bool more = p + 1 < npairs;
-      const int jn = 512 * (p + 1) + 768;
+      const int jn = 512 * (p + 1) + 768;                  // staged samples [jn, jn + 512)
       const bool nint = more && interior(jn, jn + 512);
-      float ny[8], nyp[8];
-      if (nint) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { ny[u] = raw_ld(sbase + jn + 64 * u + lane); nyp[u] = raw_ld(sbase + jn + 64 * u + lane - 1); }
-      }
 
       // ---- pass 1 + exchange 1
       f3_dft16(z, H, W1, W3);
+      if (!F3_SKIP(0x200)) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) e1w[k] = z[k];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) z[u] = e1r[68 * u];
+      for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 68 * u);
+      }
       // ---- pass 2 + exchange 2
       {
         v2 tw[8];
 #pragma unroll
-        for (int r = 1; r < 8; ++r) tw[r] = T2[r * 16 + (lane & 15)];
+        for (int r = 1; r < 8; ++r) tw[r] = ldv(T2 + r * 16 + (lane & 15));
         v2 xa[8], xb[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) { xa[r] = z[2 * r]; xb[r] = z[2 * r + 1]; }
 #pragma unroll
-        for (int r = 1; r < 8; ++r) { xa[r] = cmul(xa[r], tw[r]); xb[r] = cmul(xb[r], tw[r]); }
+        for (int r = 1; r < 8; ++r) cmul2(xa[r], tw[r], xb[r], tw[r]);
         f3_dft8(xa, H); f3_dft8(xb, H);
+        if (!F3_SKIP(0x2000)) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) { e2w[16 * r] = xa[r]; e2w[16 * r + 512] = xb[r]; }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) { z[2 * r] = xa[r]; z[2 * r + 1] = xb[r]; }
+        }
       }
       // ---- pass 3
       v2 A[8], B[8];
+      if (!F3_SKIP(0x2000)) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) { A[r] = ea[128 * r]; B[r] = eb[128 * r]; }
+      for (int r = 0; r < 8; ++r) { A[r] = ldv(ea + 128 * r); B[r] = ldv(eb + 128 * r); }
+      } else {
 #pragma unroll
-      for (int r = 1; r < 8; ++r) { A[r] = cmul(A[r], T3a[(r - 1) * 64 + lane]); B[r] = cmul(B[r], T3b[(r - 1) * 64 + lane]); }
+        for (int r = 0; r < 8; ++r) { A[r] = z[r]; B[r] = z[r + 8]; }
+      }
+#pragma unroll
+      for (int r = 1; r < 8; ++r) cmul2(A[r], ldv(T3a + (r - 1) * 64 + lane), B[r], ldv(T3b + (r - 1) * 64 + lane));
       f3_dft8(A, H); f3_dft8(B, H);
       // A[s] = Z[lane + 128 s], B[s] = Z[jb + 128 s]; the mirror of A[s] is B[7-s].  Lane 0 owns the self-mirrored
       // butterflies 0 and 64: its pairs are (A[s], A[8-s]) and (B[s], B[7-s]) -- re-seat its registers once so
@@ -298,71 +361,126 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       v2 nyq = A[4];
       if (lane == 0) { A[4] = B[4]; B[4] = A[5]; A[5] = B[5]; B[5] = A[6]; A[6] = B[6]; B[6] = A[7]; A[7] = B[7]; B[7] = A[0]; }
       // ---- |X_A|^2, |X_B|^2 -> the image as PB[bin] = (A, B)
+      if (!F3_SKIP(0x800)) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) ea[128 * s] = sqsum(A[s] + B[7 - s], A[s] - B[7 - s]);
+      for (int s = 0; s < 4; s += 2) {
+        v2 p0, p1;
+        sqsum2(A[s] + B[7 - s], A[s] - B[7 - s], A[s + 1] + B[6 - s], A[s + 1] - B[6 - s], p0, p1);
+        ea[128 * s] = p0; ea[128 * (s + 1)] = p1;
+      }
 #pragma unroll
-      for (int s = 4; s < 8; ++s) eb[384 - 128 * (s - 4)] = sqsum(A[s] + B[7 - s], A[s] - B[7 - s]);
+      for (int s = 4; s < 8; s += 2) {
+        v2 p0, p1;
+        sqsum2(A[s] + B[7 - s], A[s] - B[7 - s], A[s + 1] + B[6 - s], A[s + 1] - B[6 - s], p0, p1);
+        eb[384 - 128 * (s - 4)] = p0; eb[384 - 128 * (s - 3)] = p1;
+      }
       if (lane == 0) E[512] = v2{4.f * nyq.x * nyq.x, 4.f * nyq.y * nyq.y};
+      } else {
+        asm volatile("" :: "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(A[6]), "v"(A[7]));
+        asm volatile("" :: "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]), "v"(B[5]), "v"(B[6]), "v"(B[7]), "v"(nyq));
+      }
 
+      // ---- the next pair's 8 new rows are fetched under the mel phase (issued here, not before the FFT: 16 registers
+      // that would be live across its register peak)
+      float ny[8], nyp[8];
+      if (nint) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ny[u] = row_ld(sp + jn, 64 * u + lane); nyp[u] = row_ld(sp + jn - 1, 64 * u + lane); }
+      }
       // ---- mel + dB
       const bool vA = 2 * p < Tleft, vB = 2 * p + 1 < Tleft;
-      float* const rowA = tile + (int64_t)(2 * p) * M;
+      float* const rowA = tile + (unsigned)(2 * p * M);
+      if constexpr (NB0 > 0) {
+        if (!F3_SKIP(0x400)) {
+        const float4* pp0 = reinterpret_cast<const float4*>(E + (meta0 & 2047));
+        const float4* pp1 = reinterpret_cast<const float4*>(E + (meta1 & 2047));
+        const float4* ww0 = reinterpret_cast<const float4*>(MW) + lane;
+        const float4* ww1 = reinterpret_cast<const float4*>(MW + NB0 * 256) + lane;
+        v2 s0[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, s1[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+        for (int i = 0; i < NB0; ++i) {
+          const float4 c = ww0[64 * i], q0 = pp0[2 * i], q1 = pp0[2 * i + 1];
+          s0[0] = v2{q0.x, q0.y} * v2{c.x, c.x} + s0[0]; s0[1] = v2{q0.z, q0.w} * v2{c.y, c.y} + s0[1];
+          s0[2] = v2{q1.x, q1.y} * v2{c.z, c.z} + s0[2]; s0[3] = v2{q1.z, q1.w} * v2{c.w, c.w} + s0[3];
+        }
+#pragma unroll
+        for (int i = 0; i < NB1; ++i) {
+          const float4 c = ww1[64 * i], q0 = pp1[2 * i], q1 = pp1[2 * i + 1];
+          s1[0] = v2{q0.x, q0.y} * v2{c.x, c.x} + s1[0]; s1[1] = v2{q0.z, q0.w} * v2{c.y, c.y} + s1[1];
+          s1[2] = v2{q1.x, q1.y} * v2{c.z, c.z} + s1[2]; s1[3] = v2{q1.z, q1.w} * v2{c.w, c.w} + s1[3];
+        }
+        const v2 m0 = (s0[0] + s0[1]) + (s0[2] + s0[3]), m1 = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+        const float L00 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(m0.x, amin));
+        const float L01 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(m0.y, amin));
+        const float L10 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(m1.x, amin));
+        const float L11 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(m1.y, amin));
+        if (meta0 & (1 << 20)) {
+          const unsigned m = (meta0 >> 11) & 511;
+          rowA[m] = L00; rowA[M + m] = L01;
+          if (vA) lmax = f3_max(lmax, L00);
+          if (vB) lmax = f3_max(lmax, L01);
+        }
+        if (meta1 & (1 << 20)) {
+          const unsigned m = (meta1 >> 11) & 511;
+          rowA[m] = L10; rowA[M + m] = L11;
+          if (vA) lmax = f3_max(lmax, L10);
+          if (vB) lmax = f3_max(lmax, L11);
+        }
+        }
+      } else {
 #pragma unroll 1
-      for (int rd = 0; rd < ft.mel_rounds; ++rd) {
+      for (int rd = 0; rd < (F3_SKIP(0x400) ? 0 : n_rounds); ++rd) {
+        const uint32_t rp = ft.mel_rp[rd];                  // batches | width << 4 | weight offset << 8
         const int meta = MM[rd * 64 + lane];
-        const v2* pp = E + (meta & 2047);
-        const float4* ww = reinterpret_cast<const float4*>(MW + ft.mel_woff[rd]) + lane;
+        // taps come in fours: two 16-byte reads of (A, B) pairs (the lane's first bin is even), one 16-byte weight read
+        const float4* pp = reinterpret_cast<const float4*>(E + (meta & 2047));
+        const float4* ww = reinterpret_cast<const float4*>(MW + (rp >> 8)) + lane;
+        const int nb = rp & 15, wd = (rp >> 4) & 15;
         v2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #define F3_BATCH(i)                                                                  \
-        {                                                                            \
+        if (nb > (i)) {                                                              \
           const float4 c = ww[64 * (i)];                                             \
-          const v2 x0 = pp[4 * (i)], x1 = pp[4 * (i) + 1], x2 = pp[4 * (i) + 2], x3 = pp[4 * (i) + 3]; \
-          a0 = x0 * v2{c.x, c.x} + a0; a1 = x1 * v2{c.y, c.y} + a1;                 \
-          a0 = x2 * v2{c.z, c.z} + a0; a1 = x3 * v2{c.w, c.w} + a1;                 \
+          const float4 q0 = pp[2 * (i)], q1 = pp[2 * (i) + 1];                       \
+          a0 = v2{q0.x, q0.y} * v2{c.x, c.x} + a0; a1 = v2{q0.z, q0.w} * v2{c.y, c.y} + a1; \
+          a0 = v2{q1.x, q1.y} * v2{c.z, c.z} + a0; a1 = v2{q1.z, q1.w} * v2{c.w, c.w} + a1; \
         }
-        switch (ft.mel_nb[rd]) {
-          case 8: F3_BATCH(7)
-          case 7: F3_BATCH(6)
-          case 6: F3_BATCH(5)
-          case 5: F3_BATCH(4)
-          case 4: F3_BATCH(3)
-          case 3: F3_BATCH(2)
-          case 2: F3_BATCH(1)
-          default: F3_BATCH(0)
-        }
+        F3_BATCH(0) F3_BATCH(1) F3_BATCH(2) F3_BATCH(3) F3_BATCH(4) F3_BATCH(5) F3_BATCH(6) F3_BATCH(7)
 #undef F3_BATCH
         v2 acc = a0 + a1;
-        const int wd = ft.mel_width[rd];
         if (wd >= 2) { acc.x += F3_DPP(acc.x, 0xB1); acc.y += F3_DPP(acc.y, 0xB1); }       // lane ^ 1
         if (wd >= 4) { acc.x += F3_DPP(acc.x, 0x4E); acc.y += F3_DPP(acc.y, 0x4E); }       // lane ^ 2
         if (wd >= 8) { acc.x += F3_DPP(acc.x, 0x141); acc.y += F3_DPP(acc.y, 0x141); }     // the other quad of 8
-        const float L0 = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc.x));
-        const float L1 = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(kp.amin, acc.y));
+        const float L0 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(acc.x, amin));
+        const float L1 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(acc.y, amin));
         if (meta & (1 << 20)) {                               // this lane owns filter m
-          const int m = (meta >> 11) & 511;
+          const unsigned m = (meta >> 11) & 511;
           rowA[m] = L0; rowA[M + m] = L1;
-          if (vA) lmax = fmaxf(lmax, L0);
-          if (vB) lmax = fmaxf(lmax, L1);
+          if (vA) lmax = f3_max(lmax, L0);
+          if (vB) lmax = f3_max(lmax, L1);
         }
+      }
       }
 
       // ---- take in the next pair's 8 new rows
       if (more) {
+        float n[8];
         if (nint) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) rows[12 + u] = pre ? f3_pre1(ny[u], nyp[u], b1) : ny[u];
+          for (int u = 0; u < 8; ++u) n[u] = pre ? f3_pre1(ny[u], nyp[u], b1) : ny[u];
         } else {
 #pragma unroll 1
           for (int u = 0; u < 8; ++u) XB[64 * u + lane] = edge_sample(jn + 64 * u + lane);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) rows[12 + u] = XB[64 * u + lane];
+          for (int u = 0; u < 8; ++u) n[u] = XB[64 * u + lane];
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { R[8 + i].y = n[i]; R[12 + i] = v2{n[i], n[4 + i]}; }
       }
     }
     // ---- clip maximum of the log-mel (power_to_db's top_db reference)
     {
       float v = lmax;
-      v = fmaxf(v, F3_DPP(v, 0xB1)); v = fmaxf(v, F3_DPP(v, 0x4E)); v = fmaxf(v, F3_DPP(v, 0x141)); v = fmaxf(v, F3_DPP(v, 0x140));
+      v = f3_max(v, F3_DPP(v, 0xB1)); v = f3_max(v, F3_DPP(v, 0x4E)); v = f3_max(v, F3_DPP(v, 0x141)); v = f3_max(v, F3_DPP(v, 0x140));
       const int vi = __float_as_int(v);
       const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
       const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
@@ -385,7 +503,7 @@ int frames3_waves(const F3Tables& ft) {
   return frames3_lds_bytes(16, ft) <= 160 * 1024 ? 16 : 12;
 }
 
-template <int FMT, int WAVES>
+template <int FMT, int WAVES, int NB0, int NB1>
 static hipError_t launch_frames3_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
                                    int nblocks, const F3Tables& ft, const KParams& kp, float* logmel, int n_cu) {
   static bool attr_set[64] = {};
@@ -393,25 +511,37 @@ static hipError_t launch_frames3_t(hipStream_t s, const void* samples, ClipInfo*
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3<FMT, WAVES>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3<FMT, WAVES, NB0, NB1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
   const int grid = std::min(n_cu, (nblocks + WAVES - 1) / WAVES);
-  hipLaunchKernelGGL((k_frames3<FMT, WAVES>), dim3(grid), dim3(WAVES * 64), frames3_lds_bytes(WAVES, ft), s, samples, info,
-                     blocks, nblocks, ft, kp, logmel);
+  hipLaunchKernelGGL((k_frames3<FMT, WAVES, NB0, NB1>), dim3(grid), dim3(WAVES * 64), frames3_lds_bytes(WAVES, ft), s,
+                     samples, info, blocks, nblocks, ft, kp, logmel);
   return hipGetLastError();
+}
+
+template <int FMT, int WAVES>
+static hipError_t launch_frames3_w(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
+                                   int nblocks, const F3Tables& ft, const KParams& kp, float* logmel, int n_cu) {
+  // straight-line mel schedules compiled in: two rounds of width 1
+  const bool two = ft.mel_rounds == 2 && ((ft.mel_rp[0] >> 4) & 15) == 1 && ((ft.mel_rp[1] >> 4) & 15) == 1 &&
+                   !getenv("AFX_F3_GENERIC_MEL");
+  const int nb0 = ft.mel_rp[0] & 15, nb1 = ft.mel_rp[1] & 15;
+  if (two && nb0 == 2 && nb1 == 7)
+    return launch_frames3_t<FMT, WAVES, 2, 7>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
+  return launch_frames3_t<FMT, WAVES, 0, 0>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
 }
 
 hipError_t launch_frames3(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                           const F3Tables& ft, const KParams& kp, float* logmel, int n_cu) {
   const int waves = frames3_waves(ft);
   if (kp.fmt == AFX_FMT_S16)
-    return waves == 16 ? launch_frames3_t<AFX_FMT_S16, 16>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu)
-                       : launch_frames3_t<AFX_FMT_S16, 12>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
-  return waves == 16 ? launch_frames3_t<AFX_FMT_F32, 16>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu)
-                     : launch_frames3_t<AFX_FMT_F32, 12>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
+    return waves == 16 ? launch_frames3_w<AFX_FMT_S16, 16>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu)
+                       : launch_frames3_w<AFX_FMT_S16, 12>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
+  return waves == 16 ? launch_frames3_w<AFX_FMT_F32, 16>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu)
+                     : launch_frames3_w<AFX_FMT_F32, 12>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
 }
 
 }  // namespace afx

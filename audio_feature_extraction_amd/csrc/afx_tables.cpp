@@ -208,14 +208,17 @@ void build_f3_mel(const std::vector<float>& W, int M, int NB, int max_slot, Host
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nnz[a] < nnz[b]; });
   const int INF = 1 << 28;
   // dp[r][i]: cheapest way to place the first i filters (sorted) in r rounds
-  std::vector<std::vector<int>> dp(kF3MaxRounds + 1, std::vector<int>(M + 1, INF)), from_w = dp, from_i = dp;
+  std::vector<std::vector<int>> dp(kF3KernelRounds + 1, std::vector<int>(M + 1, INF)), from_w = dp, from_i = dp;
   dp[0][0] = 0;
+  // a lane's first bin is even (16-byte reads of two (A, B) bins): a filter starting on an odd bin takes one tap more
+  for (int m = 0; m < M; ++m) if (nnz[m] > 0 && (first[m] & 1)) { first[m] -= 1; nnz[m] += 1; }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nnz[a] < nnz[b]; });
   auto batches = [&](int i, int j, int w) {            // filters [i, j) at width w
     const int maxt = nnz[order[j - 1]];
     const int per = (maxt + w - 1) / w;
     return std::max(1, (per + 3) / 4);
   };
-  for (int r = 0; r < kF3MaxRounds; ++r)
+  for (int r = 0; r < kF3KernelRounds; ++r)
     for (int i = 0; i < M; ++i) {
       if (dp[r][i] >= INF) continue;
       for (int w = 1; w <= 8; w *= 2) {
@@ -228,7 +231,7 @@ void build_f3_mel(const std::vector<float>& W, int M, int NB, int max_slot, Host
       }
     }
   int best_r = -1;
-  for (int r = 1; r <= kF3MaxRounds; ++r) if (dp[r][M] < INF && (best_r < 0 || dp[r][M] < dp[best_r][M])) best_r = r;
+  for (int r = 1; r <= kF3KernelRounds; ++r) if (dp[r][M] < INF && (best_r < 0 || dp[r][M] < dp[best_r][M])) best_r = r;
   if (best_r < 0) return;
   std::vector<int> cut_i(best_r), cut_w(best_r);
   for (int r = best_r, j = M; r >= 1; --r) { cut_i[r - 1] = from_i[r][j]; cut_w[r - 1] = from_w[r][j]; j = from_i[r][j]; }
