@@ -26,7 +26,7 @@ K_FRAMES = 2
 SYMBOLS = (
     "afx_version", "afx_device_count", "afx_last_error", "afx_init", "afx_destroy",
     "afx_malloc", "afx_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
-    "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables",
+    "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables", "afx_build_mel_schedule",
     "afx_extract_batch", "afx_f0_batch", "afx_zcr_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings",
 )
 
@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
         L.afx_plan_create.argtypes = [vp, C.POINTER(Params), C.POINTER(vp)]
         L.afx_plan_destroy.argtypes = [vp]; L.afx_plan_destroy.restype = None
         L.afx_build_tables.argtypes = [C.POINTER(Params), vp, vp, vp]
+        L.afx_build_mel_schedule.argtypes = [C.POINTER(Params), vp, vp, vp]
         L.afx_extract_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
         L.afx_f0_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
         L.afx_zcr_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp]
@@ -136,6 +137,19 @@ def build_tables(p: Params):
     dct = np.empty((p.n_mfcc, p.n_mels), np.float32)
     _check(lib().afx_build_tables(C.byref(p), win.ctypes.data, mel.ctypes.data, dct.ctypes.data), "afx_build_tables")
     return win, mel, dct
+
+
+def build_mel_schedule(p: Params) -> dict:
+    """Host-only: the per-lane mel schedule of the wave-level frame kernel (rounds of nb batches of 4 taps)."""
+    info = np.zeros(26, np.int32)
+    _check(lib().afx_build_mel_schedule(C.byref(p), info.ctypes.data, None, None), "afx_build_mel_schedule")
+    rounds, nw = int(info[0]), int(info[1])
+    w = np.zeros(nw, np.float32)
+    meta = np.zeros(64 * rounds, np.int32)
+    _check(lib().afx_build_mel_schedule(C.byref(p), info.ctypes.data, w.ctypes.data, meta.ctypes.data), "afx_build_mel_schedule")
+    return {"rounds": rounds, "nb": [int(info[2 + 3 * r]) for r in range(rounds)],
+            "width": [int(info[3 + 3 * r]) for r in range(rounds)], "woff": [int(info[4 + 3 * r]) for r in range(rounds)],
+            "weights": w, "meta": meta.reshape(rounds, 64)}
 
 
 class DeviceBuffer:

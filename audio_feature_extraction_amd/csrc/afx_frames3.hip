@@ -181,7 +181,7 @@ __device__ __forceinline__ uint32_t f3_ord(float f) {
 #define F3_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, false))
 
 size_t frames3_lds_bytes(int waves, const F3Tables& ft) {
-  return (size_t)(waves * kF3ExFloats + kF3TabFloats + ft.mel_wfloats + ft.mel_rounds * 64) * sizeof(float);
+  return (size_t)(waves * kF3ExFloats + kF3TabFloats + ft.mel_wfloats + ft.mel_rounds * 64 + (waves > 12 ? 1024 : 0)) * sizeof(float);
 }
 
 // NB0, NB1 > 0: the mel schedule is known at compile time to be two rounds of width 1 with NB0 and NB1 batches (the
@@ -220,9 +220,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     for (int i = tid; i < ft.mel_rounds * 64; i += WAVES * 64) MM[i] = ft.mel_meta[i];
     for (int i = lane; i < kF3ExFloats; i += 64) XB[i] = 0.f;
   }
-  float wreg[16];                          // the lane's window values (w[n] = w[N - n]) x 0.5
+  // the lane's 16 window values (w[n] = w[N - n]) x 0.5: registers at 12 waves per CU; at 16 waves (128 registers per
+  // lane) a 4 KB table [u / 2][lane] of pairs, read back per frame pair
+  constexpr bool WLDS = WAVES > 12;
+  v2* const WT = reinterpret_cast<v2*>(MM + ft.mel_rounds * 64);
+  float wreg[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) wreg[u] = 0.5f * ft.window[u < 8 ? lane + 64 * u : (64 - lane) + 64 * (15 - u)];
+  if constexpr (WLDS) {
+    if (tid < 64) {
+#pragma unroll
+      for (int v = 0; v < 8; ++v) WT[v * 64 + lane] = v2{wreg[2 * v], wreg[2 * v + 1]};
+    }
+  }
   __syncthreads();
 
   const v2 H = {0.70710678118654752440f, 0.70710678118654752440f};
@@ -304,8 +314,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     for (int p = 0; p < npairs; ++p) {
       // ---- z = w yA + i w yB (frame A: rows 0..15, frame B: rows 4..19)
       v2 z[16];
+      if constexpr (WLDS) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) z[u] = R[u] * v2{wreg[u], wreg[u]};
+        for (int v = 0; v < 8; ++v) {
+          const v2 w = ldv(WT + v * 64 + lane);
+          z[2 * v] = R[2 * v] * v2{w.x, w.x}; z[2 * v + 1] = R[2 * v + 1] * v2{w.y, w.y};
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) z[u] = R[u] * v2{wreg[u], wreg[u]};
+      }
       // the next pair shares rows 8..19 and brings 8 new ones, n[0..7] = rows 20..27 of this pair's window:
       //   R'[u] = R[u + 8] (u < 8),  R'[8 + i] = (R[12 + i].y, n[i]),  R'[12 + i] = (n[i], n[4 + i])
 #pragma unroll

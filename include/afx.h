@@ -107,6 +107,14 @@ void afx_plan_destroy(afx_plan* plan);
  * table construction under librosa.feature.mfcc (F:127). */
 int afx_build_tables(const afx_params* p, float* window, float* mel_dense, float* dct);
 
+/* Host-only: the mel schedule of the wave-level frame kernel (k_frames3), for inspection and tests.
+ * One frame pair at a time, a lane accumulates 4 * nb consecutive taps of one filter of librosa.filters.mel
+ * (F:127); `width` adjacent lanes share a filter.  info[26] = rounds, weight floats, then per round (8 slots)
+ * nb, width, weight offset; weights[info[1]] as [round][batch][lane][4]; meta[64 * rounds] per lane:
+ * first bin | filter << 11 | owner << 20.  Any pointer may be NULL.  AFX_ERR_UNSUPPORTED when the
+ * configuration has no such schedule. */
+int afx_build_mel_schedule(const afx_params* p, int32_t* info, float* weights, int32_t* meta);
+
 /* ---- the hot path ---------------------------------------------------------
  * One pass of preprocess_audio -> extract_mfcc + extract_energy (F:194,198,199)
  * over a ragged batch of clips.

@@ -91,3 +91,44 @@ def test_f0_host_tables_match_the_pyin_oracle():
                     assert abs(t["lt"][0, rc, d] - logA[b, j]) < 1e-13            # voiced -> voiced (stay)
                     assert abs(t["lt"][1, rc, d] - logA[b, nb + j]) < 1e-13       # voiced -> unvoiced (switch)
                     assert abs(t["lt"][0, rc, d] - logA[nb + b, nb + j]) < 1e-13
+
+
+@pytest.mark.parametrize("sr,n_fft,n_mels", [(22050, 1024, 128), (22050, 1024, 40), (22050, 1024, 64), (16000, 1024, 128),
+                                               (44100, 1024, 256), (8000, 1024, 20)])
+def test_wave_mel_schedule_reproduces_the_filterbank(sr, n_fft, n_mels):
+    """The per-lane tap schedule of k_frames3 is a re-ordering of librosa.filters.mel: summing every lane's
+    weights back onto (filter, bin) must give the dense float32 matrix exactly, every real filter must have
+    exactly one owner lane, first bins are even (16-byte reads), and a width-1 round must not put two
+    different read addresses on one LDS slot within a ds_read_b128 lane group."""
+    p = N.make_params(sr, n_fft, n_fft // 4, 13, n_mels)
+    _, mel, _ = N.build_tables(p)
+    s = N.build_mel_schedule(p)
+    nbins = n_fft // 2 + 1
+    dense = np.zeros((n_mels, nbins + 64), np.float64)
+    owners = np.zeros(n_mels, int)
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15] + list(range(20, 28)), list(range(4, 12)) + [16, 17, 18, 19, 28, 29, 30, 31],
+              [32, 33, 34, 35, 44, 45, 46, 47] + list(range(52, 60)), list(range(36, 44)) + [48, 49, 50, 51, 60, 61, 62, 63]]
+    for r in range(s["rounds"]):
+        nb, wd = s["nb"][r], s["width"][r]
+        w = s["weights"][s["woff"][r]: s["woff"][r] + nb * 256].reshape(nb, 64, 4)
+        for lane in range(64):
+            meta = int(s["meta"][r, lane])
+            bin0, m, own = meta & 2047, (meta >> 11) & 511, (meta >> 20) & 1
+            assert bin0 % 2 == 0
+            taps = w[:, lane, :].reshape(-1)
+            if own:
+                owners[m] += 1
+            if taps.any():
+                assert m < n_mels
+                dense[m, bin0: bin0 + 4 * nb] += taps
+            assert bin0 + 4 * nb - 1 <= 1087
+        if wd == 1 and (sr, n_mels) == (22050, 128):       # the reference configuration: a perfect matching exists
+            for g in groups:
+                slots = {}
+                for lane in g:
+                    b0 = int(s["meta"][r, lane]) & 2047
+                    slots.setdefault((b0 // 2) % 16, set()).add(b0)
+                assert all(len(v) == 1 for v in slots.values()), (r, slots)
+    assert (owners == 1).all()
+    np.testing.assert_array_equal(dense[:, :nbins].astype(np.float32), mel)
+    assert not dense[:, nbins:].any()
