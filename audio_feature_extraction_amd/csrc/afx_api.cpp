@@ -47,6 +47,8 @@ struct afx_plan {
   bool use_f3 = false;
   std::vector<void*> table_allocs;
   DevBuf samples, clips, info, blocks, bsum, logmel, rms, mfcc, stats, frames, frame_offs, stamps;
+  DevBuf blocks_spec, blockmax, items, n_items;      // speculative pipeline (k_frames3 before the trim decision)
+  std::vector<BlockDesc> h_blocks;
   // extract_f0 (pYIN): tables for the last (fmin, fmax) used and the stage's workspace
   bool f0_ready = false;
   double f0_fmin = 0.0, f0_fmax = 0.0;
@@ -264,6 +266,7 @@ extern "C" void afx_plan_destroy(afx_plan* pl) {
   release(pl->samples); release(pl->clips); release(pl->info); release(pl->blocks); release(pl->bsum);
   release(pl->logmel); release(pl->rms); release(pl->mfcc); release(pl->stats); release(pl->frames);
   release(pl->frame_offs); release(pl->stamps);
+  release(pl->blocks_spec); release(pl->blockmax); release(pl->items); release(pl->n_items);
   if (pl->h_pin) (void)hipHostFree(pl->h_pin);
   if (pl->ev_ready)
     for (int k = 0; k < AFX_K_COUNT; ++k) { (void)hipEventDestroy(pl->ev[k][0]); (void)hipEventDestroy(pl->ev[k][1]); }
@@ -326,6 +329,30 @@ static int prepare_descriptors(afx_plan* pl, const int64_t* offsets, const int64
   if ((rc = ensure(pl->blocks, std::max<size_t>((size_t)nblk, 1) * sizeof(BlockDesc))) != AFX_OK) return rc;
   hipStream_t s = pl->ctx->stream;
   HIP_TRY(hipMemcpyAsync(pl->clips.p, pl->h_clips.data(), n * sizeof(ClipDesc), hipMemcpyHostToDevice, s));
+  if (pl->use_f3) {
+    // the speculative pass's blocks: every absolute 16-frame block of every clip, nothing trimmed yet
+    const int per = pl->kp.rms_sub, half = pl->p.n_fft / 2;
+    const int64_t lim = (int64_t)1 << 30;
+    pl->h_blocks.resize((size_t)std::max<int64_t>(nblk, 1));
+    for (int i = 0; i < n; ++i) {
+      const ClipDesc& c = pl->h_clips[i];
+      const int64_t ntb = (c.len + th - 1) / th;
+      for (int b = 0; b < c.tpad / kFramesPerBlock; ++b) {
+        BlockDesc& d = pl->h_blocks[(size_t)c.blk_base + b];
+        const int64_t gs = (int64_t)b * kFramesPerBlock * hop - half;       // clip sample of staged index 0
+        auto rel = [&](int64_t x) { const int64_t q = x - gs; return (int32_t)(q < -lim ? -lim : (q > lim ? lim : q)); };
+        d.sample_base = c.off + gs; d.frame_slot = c.frame_base + (int64_t)b * kFramesPerBlock; d.clip_off = c.off;
+        d.keep_lo = rel(0); d.keep_hi = rel(c.len); d.have_lo = rel(0); d.have_hi = rel(c.len);
+        d.clip = i; d.t0 = b * kFramesPerBlock; d.T = c.tmax; d.active = (c.len >= 2 && d.t0 < c.tmax) ? 1 : 0;
+        d.pad_[0] = (int32_t)(c.tblk_base * per); d.pad_[1] = (int32_t)(ntb * per);
+      }
+    }
+    if ((rc = ensure(pl->blocks_spec, pl->h_blocks.size() * sizeof(BlockDesc))) != AFX_OK) return rc;
+    if ((rc = ensure(pl->blockmax, pl->h_blocks.size() * sizeof(float))) != AFX_OK) return rc;
+    if ((rc = ensure(pl->items, (size_t)n * kF3ItemsPerClip * sizeof(BlockDesc))) != AFX_OK) return rc;
+    if ((rc = ensure(pl->n_items, 16)) != AFX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(pl->blocks_spec.p, pl->h_blocks.data(), pl->h_blocks.size() * sizeof(BlockDesc), hipMemcpyHostToDevice, s));
+  }
   HIP_TRY(hipStreamSynchronize(s));   // h_clips may be rebuilt by the next call; descriptors change rarely
   pl->c_off.assign(offsets, offsets + n);
   pl->c_len.assign(lengths, lengths + n);
@@ -383,21 +410,34 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
   ClipInfo* d_info = (ClipInfo*)pl->info.p;
 
   HIP_TRY(hipMemsetAsync(d_info, 0, n * sizeof(ClipInfo), s));
+  const bool want_stamps = getenv("AFX_DEBUG_STAMPS") != nullptr;     // diagnostic build of k_frames
+  const bool f3 = pl->use_f3 && !want_stamps && (!(kp.flags & 0x7f00) || getenv("AFX_F3_DEBUG"));
+  static const bool no_spec = getenv("AFX_NO_SPEC") != nullptr;       // A/B: the two-pass pipeline with k_frames3
+  if (f3 && !no_spec && pl->nblocks > 0) {
+    // the samples are read once: frames before the trim decision (which the same pass feeds), then the few frames a cut touches
+    const int max_items = n * kF3ItemsPerClip;
+    HIP_TRY(hipMemsetAsync(pl->n_items.p, 0, 16, s));
+    TIMED(AFX_K_FRAMES, launch_frames3(s, d_samples, d_info, (const BlockDesc*)pl->blocks_spec.p, pl->nblocks, nullptr, pl->f3, kp,
+                                       (float*)pl->logmel.p, (float*)pl->blockmax.p, (float*)pl->bsum.p, true, pl->n_cu));
+    TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide3(s, d_clips, d_info, (const float*)pl->bsum.p, (const float*)pl->blockmax.p,
+                                                 (BlockDesc*)pl->items.p, (int*)pl->n_items.p, max_items, (float*)pl->rms.p, n, kp));
+    TIMED(AFX_K_TRIM_BLOCKS, launch_frames3(s, d_samples, d_info, (const BlockDesc*)pl->items.p, max_items, (const int*)pl->n_items.p,
+                                            pl->f3, kp, (float*)pl->logmel.p, nullptr, nullptr, false, pl->n_cu));
+    TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax, true, true));
+  } else {
   TIMED(AFX_K_TRIM_BLOCKS, launch_trim_blocks(s, d_samples, d_clips, d_info, (float*)pl->bsum.p, n, pl->max_tblocks, kp));
   TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, (float*)pl->rms.p, n, kp));
   if (pl->nblocks > 0) {
     const int grid = std::min(pl->nblocks, pl->n_cu * 2);
     unsigned long long* d_stamps = nullptr;
-    const bool want_stamps = getenv("AFX_DEBUG_STAMPS") != nullptr;     // diagnostic build of k_frames
     if (want_stamps) {
       if ((rc = ensure(pl->stamps, (size_t)grid * kWaves * kStampPhases * 8)) != AFX_OK) return rc;
       d_stamps = (unsigned long long*)pl->stamps.p;
       HIP_TRY(hipMemsetAsync(d_stamps, 0, (size_t)grid * kWaves * kStampPhases * 8, s));
     }
-    const bool f3 = pl->use_f3 && !want_stamps && (!(kp.flags & 0x7f00) || getenv("AFX_F3_DEBUG"));
     if (f3)
-      TIMED(AFX_K_FRAMES, launch_frames3(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks, pl->f3, kp,
-                                         (float*)pl->logmel.p, pl->n_cu));
+      TIMED(AFX_K_FRAMES, launch_frames3(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks, nullptr, pl->f3, kp,
+                                         (float*)pl->logmel.p, nullptr, nullptr, false, pl->n_cu));
     else
       TIMED(AFX_K_FRAMES, launch_frames(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks,
                                         pl->dt, kp, (float*)pl->logmel.p, (float*)pl->rms.p, grid, d_stamps));
@@ -426,6 +466,7 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
     }
     TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax, f3));
   }
+  }
   TIMED(AFX_K_STATS, launch_stats(s, d_clips, d_info, kp, (const float*)pl->mfcc.p, (const float*)pl->rms.p,
                                   (float*)pl->stats.p, d_frames, (const int64_t*)pl->frame_offs.p, n));
 
@@ -447,6 +488,7 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
   if (pl->timing) {
     for (int k = 0; k < AFX_K_COUNT; ++k) {
       if (pl->nblocks == 0 && (k == AFX_K_FRAMES || k == AFX_K_DCT)) continue;
+      if (pl->launches[k] == 0) continue;
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, pl->ev[k][0], pl->ev[k][1]) == hipSuccess) pl->ms_sum[k] += ms;
     }

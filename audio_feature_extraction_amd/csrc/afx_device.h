@@ -92,7 +92,7 @@ hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
 constexpr int kStampPhases = 12;
 hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
                       const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax,
-                      bool frame_major = false);
+                      bool frame_major = false, bool spec = false);
 hipError_t launch_stats(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const KParams& kp,
                         const float* mfcc, const float* rms_rows, float* stats, float* frames_out,
                         const int64_t* frame_offsets, int n_clips);

@@ -44,7 +44,13 @@ void build_f3_mel(const std::vector<float>& mel_dense, int n_mels, int n_bins, i
 size_t frames3_lds_bytes(int waves, const F3Tables& ft);
 bool frames3_eligible(const KParams& kp, const F3Tables& ft);
 int frames3_waves(const F3Tables& ft);
+// spec = true: the speculative first launch over the host-built absolute blocks (emits bsum / blockmax);
+// spec = false: blocks come from a device-built list whose length is *nblocks_dev (nblocks = its capacity)
 hipError_t launch_frames3(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
-                          const F3Tables& ft, const KParams& kp, float* logmel, int n_cu);
+                          const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
+                          float* blockmax, float* bsum, bool spec, int n_cu);
+constexpr int kF3ItemsPerClip = 6;         // redo-list capacity per clip (k_trim_decide3)
+hipError_t launch_trim_decide3(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum, const float* blockmax,
+                               BlockDesc* items, int* n_items, int max_items, float* rms_rows, int n_clips, const KParams& kp);
 
 }  // namespace afx

@@ -187,12 +187,23 @@ size_t frames3_lds_bytes(int waves, const F3Tables& ft) {
 // NB0, NB1 > 0: the mel schedule is known at compile time to be two rounds of width 1 with NB0 and NB1 batches (the
 // reference's 22050 Hz / 128 mels is 2 and 7): the tap walk is then straight-line code, every LDS read of a round in
 // flight before its first FMA.  NB0 = 0: any schedule, batches behind uniform branches.
-template <int FMT, int WAVES, int NB0, int NB1>
+// SPEC (the first launch of a batch, "speculative"): blocks are the host-built absolute 16-frame blocks of every
+// clip, computed BEFORE the trim decision -- frames sit on the absolute hop grid because librosa.effects.trim cuts at
+// multiples of its own hop (512), so an interior frame does not depend on where the cut falls.  The kernel then also
+// emits what the trim decision needs, from the pre-emphasised rows it holds anyway: the sum of squares of every
+// 256-sample sub-block (bsum) and the non-finite flag; and, instead of the clip-wide atomic maximum, one log-mel
+// maximum per block (blockmax), from which k_trim_decide3 takes the clip maximum over the blocks that survive the
+// cut.  !SPEC (second launch): the few blocks around a cut (device-built list, count in *nblocks_dev), frames
+// recomputed with the trimmed span masked, maxima merged by atomicMax.  The samples are thus read once per batch.
+template <int FMT, int WAVES, int NB0, int NB1, bool SPEC>
 __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__ samples,
                                                         ClipInfo* __restrict__ info,
                                                         const BlockDesc* __restrict__ blocks, int nblocks,
+                                                        const int* __restrict__ nblocks_dev,
                                                         F3Tables ft, KParams kp,
-                                                        float* __restrict__ logmel) {
+                                                        float* __restrict__ logmel,
+                                                        float* __restrict__ blockmax,
+                                                        float* __restrict__ bsum) {
   constexpr int N = 1024, HOP = 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -263,6 +274,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
   const int meta0 = MM[lane], meta1 = MM[64 + lane];       // straight-line schedule: the lane's two filters
   const float amin = kp.amin;
 
+  if (nblocks_dev) nblocks = *nblocks_dev;
+  // sum of squares of four rows (one 256-sample sub-block of the pre-emphasised signal), wave-wide; sub-block j of the
+  // clip goes to bsum[base + j] when the clip has such a slot.  A non-finite sum makes the wave look at its rows.
+  auto subblock = [&](float r0, float r1, float r2, float r3, const BlockDesc& bd, int j) {
+    float q = r0 * r0; q = fmaf(r1, r1, q); q = fmaf(r2, r2, q); q = fmaf(r3, r3, q);
+    q += F3_DPP(q, 0xB1); q += F3_DPP(q, 0x4E); q += F3_DPP(q, 0x141); q += F3_DPP(q, 0x140);
+    const int qi = __float_as_int(q);
+    const float t = (__int_as_float(__builtin_amdgcn_readlane(qi, 0)) + __int_as_float(__builtin_amdgcn_readlane(qi, 16))) +
+                    (__int_as_float(__builtin_amdgcn_readlane(qi, 32)) + __int_as_float(__builtin_amdgcn_readlane(qi, 48)));
+    if (j >= 0 && j < bd.pad_[1]) {
+      if (lane == 0) bsum[bd.pad_[0] + j] = t;
+      if (!(fabsf(t) < INFINITY)) {
+        const bool bad = !(isfinite(r0) && isfinite(r1) && isfinite(r2) && isfinite(r3));
+        if (__any(bad) && lane == 0) atomicOr(&info[bd.clip].nonfinite, 1u);
+      }
+    }
+  };
+
   const int total_waves = gridDim.x * WAVES;
   for (int b = blockIdx.x * WAVES + wave; b < nblocks; b += total_waves) {
     const BlockDesc bd = blocks[b];
@@ -306,6 +335,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) R[u] = v2{rows[u], rows[u + 4]};
+      if constexpr (SPEC) {
+        // rows 8..11 / 12..15 / 16..19 are sub-blocks t0, t0 + 1, t0 + 2 of the clip; the first belongs to the
+        // previous block's last pair unless this is the clip's first block
+        if (bd.t0 == 0) subblock(rows[8], rows[9], rows[10], rows[11], bd, 0);
+        subblock(rows[12], rows[13], rows[14], rows[15], bd, bd.t0 + 1);
+        subblock(rows[16], rows[17], rows[18], rows[19], bd, bd.t0 + 2);
+      }
     }
     float lmax = -INFINITY;
     float* const tile = logmel + bd.frame_slot * (int64_t)M;     // [frame][mel]
@@ -434,13 +470,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         const float L11 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(m1.y, amin));
         if (meta0 & (1 << 20)) {
           const unsigned m = (meta0 >> 11) & 511;
-          rowA[m] = L00; rowA[M + m] = L01;
+          if (vA) rowA[m] = L00;
+          if (vB) rowA[M + m] = L01;
           if (vA) lmax = f3_max(lmax, L00);
           if (vB) lmax = f3_max(lmax, L01);
         }
         if (meta1 & (1 << 20)) {
           const unsigned m = (meta1 >> 11) & 511;
-          rowA[m] = L10; rowA[M + m] = L11;
+          if (vA) rowA[m] = L10;
+          if (vB) rowA[M + m] = L11;
           if (vA) lmax = f3_max(lmax, L10);
           if (vB) lmax = f3_max(lmax, L11);
         }
@@ -472,7 +510,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         const float L1 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(acc.y, amin));
         if (meta & (1 << 20)) {                               // this lane owns filter m
           const unsigned m = (meta >> 11) & 511;
-          rowA[m] = L0; rowA[M + m] = L1;
+          if (vA) rowA[m] = L0;
+          if (vB) rowA[M + m] = L1;
           if (vA) lmax = f3_max(lmax, L0);
           if (vB) lmax = f3_max(lmax, L1);
         }
@@ -493,6 +532,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { R[8 + i].y = n[i]; R[12 + i] = v2{n[i], n[4 + i]}; }
+        if constexpr (SPEC) {          // rows 12..19 of pair p + 1: sub-blocks t0 + 2 (p + 1) + 1, + 2
+          subblock(n[0], n[1], n[2], n[3], bd, bd.t0 + 2 * p + 3);
+          subblock(n[4], n[5], n[6], n[7], bd, bd.t0 + 2 * p + 4);
+        }
       }
     }
     // ---- clip maximum of the log-mel (power_to_db's top_db reference)
@@ -503,7 +546,147 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
       const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
       const float mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-      if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx));
+      if constexpr (SPEC) { if (lane == 0) blockmax[b] = mx; }
+      else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx)); }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// k_trim_decide3: the trim decision AFTER the speculative frame pass.  One workgroup per clip:
+//   * librosa.effects.trim(top_db) on the sub-block sums k_frames3<SPEC> left in bsum (feature_extractor.py:72), exactly
+//     as k_trim_decide does it -> [start, end), T, status; RMS rows from the same sums (:164);
+//   * the clip's log-mel maximum (power_to_db's top_db reference) over the blocks the cut leaves untouched;
+//   * the frames the cut does touch -- the two frames whose window crosses `start`, the two that cross `end`, and
+//     the rest of their 16-frame blocks (a block maximum cannot be taken apart) -- as a list of up to-16-frame items
+//     for the second k_frames3 launch.
+// Frame t of the trimmed clip is absolute frame start / hop + t: later kernels read the spill at that offset.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float td3_frame_rms(const float* bs, int64_t t, int64_t nb, int half, int per, float inv_n) {
+  float s = 0.f;
+  for (int64_t b = (t - half) * per; b < (t + half) * per; ++b)
+    if (b >= 0 && b < nb * per) s += bs[b];
+  return sqrtf(s * inv_n);
+}
+
+__global__ __launch_bounds__(256) void k_trim_decide3(const ClipDesc* __restrict__ clips, ClipInfo* __restrict__ info,
+                                                      const float* __restrict__ bsum, const float* __restrict__ blockmax,
+                                                      BlockDesc* __restrict__ items, int* __restrict__ n_items, int max_items,
+                                                      float* __restrict__ rms_rows, KParams kp) {
+  __shared__ float red_f[4];
+  __shared__ long long red_a[4], red_b[4];
+  const int clip = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const ClipDesc cd = clips[clip];
+  const int64_t N = cd.len;
+  const uint32_t nonfinite = info[clip].nonfinite;
+  int status = AFX_CLIP_OK;
+  if (N < 2) status = AFX_CLIP_TOO_SHORT;
+  else if (nonfinite) status = AFX_CLIP_NONFINITE;
+  int64_t start = 0, end = N;
+  const int per = kp.rms_sub;
+  auto wave_maxf = [&](float v) {
+    v = fmaxf(v, F3_DPP(v, 0xB1)); v = fmaxf(v, F3_DPP(v, 0x4E)); v = fmaxf(v, F3_DPP(v, 0x141)); v = fmaxf(v, F3_DPP(v, 0x140));
+    const int vi = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(vi, 0)), __int_as_float(__builtin_amdgcn_readlane(vi, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(vi, 32)), __int_as_float(__builtin_amdgcn_readlane(vi, 48))));
+  };
+  if ((kp.flags & AFX_FLAG_TRIM) && status == AFX_CLIP_OK) {   // uniform per workgroup
+    const int th = kp.trim_hop, half = (kp.trim_frame / th) / 2;
+    const int64_t nb = (N + th - 1) / th, nt = 1 + N / th;
+    const float inv_n = 1.0f / (float)kp.trim_frame;
+    const float* bs = bsum + cd.tblk_base * per;
+    float mx = 0.f;
+    for (int64_t t = tid; t < nt; t += 256) mx = fmaxf(mx, td3_frame_rms(bs, t, nb, half, per, inv_n));
+    mx = wave_maxf(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    __syncthreads();
+    const float ref_db = 10.0f * log10f(fmaxf(1e-10f, mx * mx));      // amplitude_to_db(mse, ref=np.max, amin=1e-5, top_db=None)
+    long long first = (long long)1 << 62, last = -1;
+    for (int64_t t = tid; t < nt; t += 256) {
+      const float r = td3_frame_rms(bs, t, nb, half, per, inv_n);
+      const float db = 10.0f * log10f(fmaxf(1e-10f, r * r)) - ref_db;
+      if (db > -kp.trim_top_db) { if (t < first) first = t; if (t > last) last = t; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const long long f2 = __shfl_xor(first, o), l2 = __shfl_xor(last, o);
+      first = f2 < first ? f2 : first; last = l2 > last ? l2 : last;
+    }
+    if (lane == 0) { red_a[wave] = first; red_b[wave] = last; }
+    __syncthreads();
+    first = red_a[0]; last = red_b[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { first = red_a[w] < first ? red_a[w] : first; last = red_b[w] > last ? red_b[w] : last; }
+    if (last >= 0) { start = first * th; end = (last + 1) * th < N ? (last + 1) * th : N; }
+    else { start = 0; end = 0; }
+  }
+  const int hop = kp.hop;
+  const int T = (int)(1 + (end - start) / hop);
+  if (status == AFX_CLIP_OK && T < 9) status = AFX_CLIP_TOO_SHORT;   // librosa.feature.delta width 9
+  // ---- which blocks of the speculative pass stand
+  const int g0 = (int)(start / hop), glast = g0 + T - 1;
+  const int nblk = cd.tpad / kFramesPerBlock;
+  const bool cutL = start > 0, cutR = end < N;
+  const int bLo = cutL ? (g0 + 2 + 15) >> 4 : 0;
+  const int bHi = cutR ? (glast >= 17 ? (glast - 17) >> 4 : -1) : nblk - 1;
+  float cm = -INFINITY;
+  if (status == AFX_CLIP_OK)
+    for (int b = bLo + tid; b <= bHi; b += 256) cm = fmaxf(cm, blockmax[cd.blk_base + b]);
+  cm = wave_maxf(cm);
+  if (lane == 0) red_f[wave] = cm;
+  __syncthreads();
+  cm = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+  if (tid == 0) {
+    ClipInfo ci;
+    ci.start = start; ci.end = end; ci.T = T; ci.status = status;
+    ci.lmax_ord = cm > -INFINITY ? f3_ord(cm) : 0u;
+    ci.nonfinite = nonfinite;
+    info[clip] = ci;
+    // ---- frames to redo: [g0, 16 bLo) on a cut left side, [16 (bHi + 1), glast] on a cut right side
+    if (status == AFX_CLIP_OK && (cutL || cutR)) {
+      int r0[2], r1[2], nr = 0;
+      if (bLo > bHi) { r0[0] = g0; r1[0] = glast + 1; nr = 1; }
+      else {
+        if (cutL && 16 * bLo > g0) { r0[nr] = g0; r1[nr] = 16 * bLo < glast + 1 ? 16 * bLo : glast + 1; ++nr; }
+        if (cutR && 16 * (bHi + 1) <= glast) { r0[nr] = 16 * (bHi + 1) > g0 ? 16 * (bHi + 1) : g0; r1[nr] = glast + 1; ++nr; }
+      }
+      int cnt = 0;
+      for (int r = 0; r < nr; ++r) cnt += (r1[r] - r0[r] + 15) / 16;
+      if (cnt > 0) {
+        const int at = atomicAdd(n_items, cnt);
+        int k = 0;
+        const int64_t lim = (int64_t)1 << 30;
+        for (int r = 0; r < nr; ++r)
+          for (int gf = r0[r]; gf < r1[r]; gf += 16, ++k) {
+            if (at + k >= max_items) break;                 // cannot happen: the list holds 6 items per clip
+            const int nfr = r1[r] - gf < 16 ? r1[r] - gf : 16;
+            const int64_t gs = (int64_t)gf * hop - kp.n_fft / 2;
+            auto rel = [&](int64_t x) { const int64_t q = x - gs; return (int32_t)(q < -lim ? -lim : (q > lim ? lim : q)); };
+            BlockDesc d;
+            d.sample_base = cd.off + gs; d.frame_slot = cd.frame_base + gf; d.clip_off = cd.off;
+            d.keep_lo = rel(start); d.keep_hi = rel(end); d.have_lo = rel(0); d.have_hi = rel(N);
+            d.clip = clip; d.t0 = 0; d.T = nfr; d.active = 1; d.pad_[0] = 0; d.pad_[1] = 0;
+            items[at + k] = d;
+          }
+      }
+    }
+  }
+  // ---- RMS rows from the sub-block sums (feature_extractor.py:164, librosa.feature.rms center=True), trimmed frame index
+  if (rms_rows && status == AFX_CLIP_OK) {
+    const float* bs = bsum + cd.tblk_base * per;
+    const int64_t s_lo = start / hop, s_hi = (end + hop - 1) / hop;
+    const int nsb = kp.n_fft / hop, back = nsb / 2;
+    const float inv_n = 1.0f / (float)kp.n_fft;
+    for (int t = tid; t < T; t += 256) {
+      float sacc = 0.f;
+      for (int k = 0; k < nsb; ++k) {
+        const int64_t sb = s_lo + t - back + k;
+        if (sb >= s_lo && sb < s_hi) sacc += bs[sb];
+      }
+      rms_rows[cd.frame_base + t] = sqrtf(sacc * inv_n);
     }
   }
 }
@@ -521,45 +704,57 @@ int frames3_waves(const F3Tables& ft) {
   return frames3_lds_bytes(16, ft) <= 160 * 1024 ? 16 : 12;
 }
 
-template <int FMT, int WAVES, int NB0, int NB1>
+template <int FMT, int WAVES, int NB0, int NB1, bool SPEC>
 static hipError_t launch_frames3_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
-                                   int nblocks, const F3Tables& ft, const KParams& kp, float* logmel, int n_cu) {
+                                   int nblocks, const int* nblocks_dev, const F3Tables& ft, const KParams& kp,
+                                   float* logmel, float* blockmax, float* bsum, int n_cu) {
   static bool attr_set[64] = {};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3<FMT, WAVES, NB0, NB1>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3<FMT, WAVES, NB0, NB1, SPEC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  const int grid = std::min(n_cu, (nblocks + WAVES - 1) / WAVES);
-  hipLaunchKernelGGL((k_frames3<FMT, WAVES, NB0, NB1>), dim3(grid), dim3(WAVES * 64), frames3_lds_bytes(WAVES, ft), s,
-                     samples, info, blocks, nblocks, ft, kp, logmel);
+  const int grid = std::max(1, std::min(n_cu, (nblocks + WAVES - 1) / WAVES));
+  hipLaunchKernelGGL((k_frames3<FMT, WAVES, NB0, NB1, SPEC>), dim3(grid), dim3(WAVES * 64), frames3_lds_bytes(WAVES, ft), s,
+                     samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum);
   return hipGetLastError();
 }
 
-template <int FMT, int WAVES>
+template <int FMT, int WAVES, bool SPEC>
 static hipError_t launch_frames3_w(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
-                                   int nblocks, const F3Tables& ft, const KParams& kp, float* logmel, int n_cu) {
+                                   int nblocks, const int* nblocks_dev, const F3Tables& ft, const KParams& kp,
+                                   float* logmel, float* blockmax, float* bsum, int n_cu) {
   // straight-line mel schedules compiled in: two rounds of width 1
   const bool two = ft.mel_rounds == 2 && ((ft.mel_rp[0] >> 4) & 15) == 1 && ((ft.mel_rp[1] >> 4) & 15) == 1 &&
                    !getenv("AFX_F3_GENERIC_MEL");
   const int nb0 = ft.mel_rp[0] & 15, nb1 = ft.mel_rp[1] & 15;
   if (two && nb0 == 2 && nb1 == 7)
-    return launch_frames3_t<FMT, WAVES, 2, 7>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
-  return launch_frames3_t<FMT, WAVES, 0, 0>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
+    return launch_frames3_t<FMT, WAVES, 2, 7, SPEC>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu);
+  return launch_frames3_t<FMT, WAVES, 0, 0, SPEC>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu);
 }
 
+// spec: the speculative first launch (host-built blocks; emits bsum / blockmax); otherwise the list launch
 hipError_t launch_frames3(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
-                          const F3Tables& ft, const KParams& kp, float* logmel, int n_cu) {
+                          const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
+                          float* blockmax, float* bsum, bool spec, int n_cu) {
   const int waves = frames3_waves(ft);
-  if (kp.fmt == AFX_FMT_S16)
-    return waves == 16 ? launch_frames3_w<AFX_FMT_S16, 16>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu)
-                       : launch_frames3_w<AFX_FMT_S16, 12>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
-  return waves == 16 ? launch_frames3_w<AFX_FMT_F32, 16>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu)
-                     : launch_frames3_w<AFX_FMT_F32, 12>(s, samples, info, blocks, nblocks, ft, kp, logmel, n_cu);
+#define AFX_F3_GO(FMT, W)                                                                                                   \
+  (spec ? launch_frames3_w<FMT, W, true>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu) \
+        : launch_frames3_w<FMT, W, false>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu))
+  if (kp.fmt == AFX_FMT_S16) return waves == 16 ? AFX_F3_GO(AFX_FMT_S16, 16) : AFX_F3_GO(AFX_FMT_S16, 12);
+  return waves == 16 ? AFX_F3_GO(AFX_FMT_F32, 16) : AFX_F3_GO(AFX_FMT_F32, 12);
+#undef AFX_F3_GO
+}
+
+hipError_t launch_trim_decide3(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum, const float* blockmax,
+                               BlockDesc* items, int* n_items, int max_items, float* rms_rows, int n_clips, const KParams& kp) {
+  hipLaunchKernelGGL(k_trim_decide3, dim3(n_clips), dim3(256), 0, s, clips, info, bsum, blockmax, items, n_items, max_items,
+                     rms_rows, kp);
+  return hipGetLastError();
 }
 
 }  // namespace afx

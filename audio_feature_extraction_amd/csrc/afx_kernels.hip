@@ -1534,7 +1534,7 @@ __global__ __launch_bounds__(256) void k_dct(const ClipDesc* __restrict__ clips,
                                              const ClipInfo* __restrict__ info,
                                              const float* __restrict__ dctA, KParams kp,
                                              const float* __restrict__ logmel,
-                                             float* __restrict__ mfcc) {
+                                             float* __restrict__ mfcc, int spec) {
   const int clip = blockIdx.y;
   const ClipInfo ci = info[clip];
   if (ci.status != AFX_CLIP_OK) return;
@@ -1547,7 +1547,9 @@ __global__ __launch_bounds__(256) void k_dct(const ClipDesc* __restrict__ clips,
   const int f = lane & 15, q = lane >> 4;
   // tile layout [mel/4][frame][mel%4]: B[k = q][j = f] of k-step i is at 64 i + 4 f + q (one 256-B row per step)
   // FM (k_frames3's spill): frame-major [frame][mel], B[k = q][j = f] of k-step i is mel 4 i + q of frame t0 + f
-  const float* tile = FM ? logmel + (cd.frame_base + t0 + f) * (int64_t)M + q
+  // spec: the spill holds absolute frames (k_frames3 ran before the trim decision); trimmed frame t is frame start / hop + t
+  const int g0 = spec ? (int)(ci.start / kp.hop) : 0;
+  const float* tile = FM ? logmel + (cd.frame_base + g0 + t0 + f) * (int64_t)M + q
                          : logmel + (cd.frame_base + t0) * (int64_t)M + f * 4 + q;
   f32x4 acc[NCG];
 #pragma unroll
@@ -1580,7 +1582,7 @@ __global__ __launch_bounds__(256) void k_dct16(const ClipDesc* __restrict__ clip
                                                const ClipInfo* __restrict__ info,
                                                const float* __restrict__ dctP, KParams kp,
                                                const float* __restrict__ logmel,
-                                               float* __restrict__ mfcc) {
+                                               float* __restrict__ mfcc, int spec) {
   const int clip = blockIdx.y;
   const ClipInfo ci = info[clip];
   if (ci.status != AFX_CLIP_OK) return;
@@ -1597,7 +1599,7 @@ __global__ __launch_bounds__(256) void k_dct16(const ClipDesc* __restrict__ clip
     const int t0 = (tile0 + j) * 16;
     // tiles past the clip's last frame are not read (t0 is wave-uniform); [mel/4][frame][mel%4]: quad row 4 s + q
     // FM: frame-major [frame][mel] -- the same four filters 16 s + 4 q + {0..3} of frame f, 16 bytes at mel offset 16 s + 4 q
-    const float* tile = FM ? logmel + (cd.frame_base + t0 + f) * (int64_t)M + q * 4
+    const float* tile = FM ? logmel + (cd.frame_base + (spec ? (int)(ci.start / kp.hop) : 0) + t0 + f) * (int64_t)M + q * 4
                            : logmel + (cd.frame_base + t0) * (int64_t)M + (q * 16 + f) * 4;
 #pragma unroll
     for (int s = 0; s < 8; ++s)
@@ -1858,34 +1860,35 @@ hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
 
 template <bool FM>
 static hipError_t launch_dct_t(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
-                               const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax) {
+                               const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax, int spec) {
   if (tb.dctP && kp.n_mels % 16 == 0 && kp.n_mels <= 128 && kp.n_mfcc <= 48) {
     dim3 g16(((max_tmax + 15) / 16 + 4 * kDctTiles - 1) / (4 * kDctTiles), n_clips);
     const int ncg = (kp.n_mfcc + 15) / 16;
-    if (ncg == 1) hipLaunchKernelGGL((k_dct16<1, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
-    else if (ncg == 2) hipLaunchKernelGGL((k_dct16<2, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
-    else hipLaunchKernelGGL((k_dct16<3, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc);
+    if (ncg == 1) hipLaunchKernelGGL((k_dct16<1, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
+    else if (ncg == 2) hipLaunchKernelGGL((k_dct16<2, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
+    else hipLaunchKernelGGL((k_dct16<3, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
     return hipGetLastError();
   }
   dim3 grid(((max_tmax + 15) / 16 + 3) / 4, n_clips);
   switch (tb.n_cgroups) {
-    case 1: hipLaunchKernelGGL((k_dct<1, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 2: hipLaunchKernelGGL((k_dct<2, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 3: hipLaunchKernelGGL((k_dct<3, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 4: hipLaunchKernelGGL((k_dct<4, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 5: hipLaunchKernelGGL((k_dct<5, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 6: hipLaunchKernelGGL((k_dct<6, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 7: hipLaunchKernelGGL((k_dct<7, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
-    case 8: hipLaunchKernelGGL((k_dct<8, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc); break;
+    case 1: hipLaunchKernelGGL((k_dct<1, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc, spec); break;
+    case 2: hipLaunchKernelGGL((k_dct<2, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc, spec); break;
+    case 3: hipLaunchKernelGGL((k_dct<3, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc, spec); break;
+    case 4: hipLaunchKernelGGL((k_dct<4, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc, spec); break;
+    case 5: hipLaunchKernelGGL((k_dct<5, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc, spec); break;
+    case 6: hipLaunchKernelGGL((k_dct<6, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc, spec); break;
+    case 7: hipLaunchKernelGGL((k_dct<7, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc, spec); break;
+    case 8: hipLaunchKernelGGL((k_dct<8, FM>), grid, dim3(256), 0, s, clips, info, tb.dctA, kp, logmel, mfcc, spec); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
 hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
-                      const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax, bool frame_major) {
-  return frame_major ? launch_dct_t<true>(s, clips, info, tb, kp, logmel, mfcc, n_clips, max_tmax)
-                     : launch_dct_t<false>(s, clips, info, tb, kp, logmel, mfcc, n_clips, max_tmax);
+                      const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax, bool frame_major,
+                      bool spec) {
+  return frame_major ? launch_dct_t<true>(s, clips, info, tb, kp, logmel, mfcc, n_clips, max_tmax, spec ? 1 : 0)
+                     : launch_dct_t<false>(s, clips, info, tb, kp, logmel, mfcc, n_clips, max_tmax, 0);
 }
 
 hipError_t launch_stats(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const KParams& kp,
