@@ -75,6 +75,14 @@ __device__ __forceinline__ v2 cmul_s(v2 v, v2 w) {
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(v), "s"(w), "v"(t));
   return d;
 }
+__device__ __forceinline__ void cmul2_s(v2& a, v2 wa, v2& b, v2 wb) {
+  v2 ta, tb, da, db;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(ta) : "v"(a), "s"(wa));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(tb) : "v"(b), "s"(wb));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(da) : "v"(a), "s"(wa), "v"(ta));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(db) : "v"(b), "s"(wb), "v"(tb));
+  a = da; b = db;
+}
 // b + (-i) h e  and  b + i h e   (h = H.x)
 __device__ __forceinline__ v2 fma_mi(v2 e, v2 H, v2 b) {
   v2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(e), "s"(H), "v"(b)); return d;
@@ -140,7 +148,9 @@ __device__ __forceinline__ void f3_dft16(v2* x, const v2 H, const v2 W1, const v
     x[0] = t0[0]; x[4] = t0[1]; x[8] = t0[2]; x[12] = t0[3];
   }
   {   // k1 = 1: twiddles W16^1, W16^2 = h (1 - i), W16^3
-    const v2 p1 = cmul_s(t1[1], W1), p3 = cmul_s(t1[3], W3), q = add_mi(t1[2], t1[2]);
+    v2 p1 = t1[1], p3 = t1[3];
+    cmul2_s(p1, W1, p3, W3);
+    const v2 q = add_mi(t1[2], t1[2]);
     const v2 a = q * H + t1[0], b = t1[0] - q * H, c = p1 + p3, e = p1 - p3;
     x[1] = a + c; x[9] = a - c; x[5] = add_mi(b, e); x[13] = add_pi(b, e);
   }
@@ -151,7 +161,9 @@ __device__ __forceinline__ void f3_dft16(v2* x, const v2 H, const v2 W1, const v
     x[2] = c * H + a; x[10] = a - c * H; x[6] = fma_mi(e, H, b); x[14] = fma_pi(e, H, b);
   }
   {   // k1 = 3: twiddles W16^3, W16^6, W16^9 = -W16^1
-    const v2 p1 = cmul_s(t3[1], W3), m3 = cmul_s(t3[3], W1), q = add_pi(t3[2], t3[2]);
+    v2 p1 = t3[1], m3 = t3[3];
+    cmul2_s(p1, W3, m3, W1);
+    const v2 q = add_pi(t3[2], t3[2]);
     const v2 a = t3[0] - q * H, b = q * H + t3[0], c = p1 - m3, e = p1 + m3;
     x[3] = a + c; x[11] = a - c; x[7] = add_mi(b, e); x[15] = add_pi(b, e);
   }
@@ -181,7 +193,7 @@ __device__ __forceinline__ uint32_t f3_ord(float f) {
 #define F3_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, false))
 
 size_t frames3_lds_bytes(int waves, const F3Tables& ft) {
-  return (size_t)(waves * kF3ExFloats + kF3TabFloats + ft.mel_wfloats + ft.mel_rounds * 64 + (waves > 12 ? 1024 : 0)) * sizeof(float);
+  return (size_t)(waves * kF3ExFloats + kF3TabFloats + ft.mel_wfloats + ft.mel_rounds * 64 + 1024) * sizeof(float);
 }
 
 // NB0, NB1 > 0: the mel schedule is known at compile time to be two rounds of width 1 with NB0 and NB1 batches (the
@@ -231,9 +243,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     for (int i = tid; i < ft.mel_rounds * 64; i += WAVES * 64) MM[i] = ft.mel_meta[i];
     for (int i = lane; i < kF3ExFloats; i += 64) XB[i] = 0.f;
   }
-  // the lane's 16 window values (w[n] = w[N - n]) x 0.5: registers at 12 waves per CU; at 16 waves (128 registers per
-  // lane) a 4 KB table [u / 2][lane] of pairs, read back per frame pair
-  constexpr bool WLDS = WAVES > 12;
+  // the lane's 16 window values (w[n] = w[N - n]) x 0.5 as a 4 KB table [u / 2][lane] of pairs, read back per frame pair:
+  // 16 registers less, so that the kernel fits 128 registers at 16 waves per CU and, at 12 waves, leaves the other
+  // streams' bandwidth-bound kernels (DCT 74 registers, statistics 56) room to run beside it on the same SIMDs
+  constexpr bool WLDS = true;
   v2* const WT = reinterpret_cast<v2*>(MM + ft.mel_rounds * 64);
   float wreg[16];
 #pragma unroll
@@ -245,7 +258,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     }
   }
   __syncthreads();
-
   const v2 H = {0.70710678118654752440f, 0.70710678118654752440f};
   const v2 W1 = {0.92387953251128675613f, -0.38268343236508977173f};      // W16^1
   const v2 W3 = {0.38268343236508977173f, -0.92387953251128675613f};      // W16^3
