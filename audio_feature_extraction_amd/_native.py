@@ -221,6 +221,10 @@ class Plan:
         except Exception:
             pass
 
+    def device_buffer(self, nbytes: int) -> "DeviceBuffer":
+        """HBM allocation on this plan's device (the seam parallel.process_files uploads a window through)."""
+        return DeviceBuffer(self.ctx, nbytes)
+
     def set_timing(self, on: bool):
         _check(lib().afx_plan_set_timing(self.handle, 1 if on else 0), "afx_plan_set_timing")
 

@@ -73,6 +73,28 @@ struct afx_plan {
   int n_cu = 256;
 };
 
+// Developer switches, read once per process (never on the per-call path): timing-only ablation bits for the frame
+// kernels, the per-phase stamp build of k_frames, the ablation build of k_frames3, and test-only chunk sizes that let
+// the multi-chunk paths be exercised with small batches.
+struct DevEnv {
+  int debug_skip = 0, f0_debug = 0;
+  bool stamps = false, f3_debug = false, no_spec = false;
+  int chunk_clips = 32768;
+  int64_t f0_chunk_frames = 1280 * 1024;
+  const char* f0_dump = nullptr;
+  DevEnv() {
+    if (const char* v = getenv("AFX_DEBUG_SKIP")) debug_skip = atoi(v) & 127;
+    if (const char* v = getenv("AFX_F0_DEBUG")) f0_debug = atoi(v);
+    stamps = getenv("AFX_DEBUG_STAMPS") != nullptr;
+    f3_debug = getenv("AFX_F3_DEBUG") != nullptr;
+    no_spec = getenv("AFX_NO_SPEC") != nullptr;
+    if (const char* v = getenv("AFX_TEST_CHUNK_CLIPS")) chunk_clips = std::max(1, std::min(32768, atoi(v)));
+    if (const char* v = getenv("AFX_TEST_F0_CHUNK_FRAMES")) f0_chunk_frames = std::max<int64_t>(64, atoll(v));
+    f0_dump = getenv("AFX_F0_DUMP");
+  }
+};
+static const DevEnv& dev_env() { static const DevEnv e; return e; }
+
 #define HIP_TRY(expr)                                                                  \
   do {                                                                                 \
     hipError_t e__ = (expr);                                                           \
@@ -391,28 +413,38 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
   if ((rc = ensure(pl->rms, (size_t)pl->total_tpad * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->mfcc, (size_t)pl->total_tpad * K * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->stats, (size_t)n * nstat * sizeof(float))) != AFX_OK) return rc;
+  // Per-frame output: this chunk's clips occupy [f_lo, f_hi) of the caller's buffer.  The device copy holds exactly that
+  // range (offsets rebased), so that a later chunk never touches -- or copies stale device memory over -- an earlier one's rows.
   float* d_frames = nullptr;
-  size_t frames_floats = 0;
+  int64_t f_lo = 0, f_hi = 0;
+  std::vector<int64_t> rebased;
   if (out_frames) {
     if (!frame_offsets) { set_error("out_frames given without frame_offsets"); return AFX_ERR_INVALID; }
-    for (int i = 0; i < n; ++i)
-      frames_floats = std::max<size_t>(frames_floats, (size_t)frame_offsets[i] + (size_t)(3 * K + 1) * pl->h_clips[i].tmax);
-    if ((rc = ensure(pl->frames, frames_floats * sizeof(float))) != AFX_OK) return rc;
+    f_lo = INT64_MAX;
+    for (int i = 0; i < n; ++i) {
+      if (frame_offsets[i] < 0) { set_error("negative frame offset"); return AFX_ERR_INVALID; }
+      f_lo = std::min(f_lo, frame_offsets[i]);
+      f_hi = std::max(f_hi, frame_offsets[i] + (int64_t)(3 * K + 1) * pl->h_clips[i].tmax);
+    }
+    rebased.resize(n);
+    for (int i = 0; i < n; ++i) rebased[i] = frame_offsets[i] - f_lo;
+    if ((rc = ensure(pl->frames, (size_t)(f_hi - f_lo) * sizeof(float))) != AFX_OK) return rc;
     if ((rc = ensure(pl->frame_offs, n * sizeof(int64_t))) != AFX_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(pl->frame_offs.p, frame_offsets, n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(pl->frame_offs.p, rebased.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(pl->frames.p, 0, (size_t)(f_hi - f_lo) * sizeof(float), s));
     d_frames = (float*)pl->frames.p;
   }
 
   KParams kp = pl->kp;
   kp.flags = flags; kp.fmt = fmt;
-  if (const char* dbg = getenv("AFX_DEBUG_SKIP")) kp.flags |= (atoi(dbg) & 127) << 8;   // timing ablation only
+  kp.flags |= dev_env().debug_skip << 8;   // timing ablation only (0 unless AFX_DEBUG_SKIP was set when the library loaded)
   const ClipDesc* d_clips = (const ClipDesc*)pl->clips.p;
   ClipInfo* d_info = (ClipInfo*)pl->info.p;
 
   HIP_TRY(hipMemsetAsync(d_info, 0, n * sizeof(ClipInfo), s));
-  const bool want_stamps = getenv("AFX_DEBUG_STAMPS") != nullptr;     // diagnostic build of k_frames
-  const bool f3 = pl->use_f3 && !want_stamps && (!(kp.flags & 0x7f00) || getenv("AFX_F3_DEBUG"));
-  static const bool no_spec = getenv("AFX_NO_SPEC") != nullptr;       // A/B: the two-pass pipeline with k_frames3
+  const bool want_stamps = dev_env().stamps;     // diagnostic build of k_frames
+  const bool f3 = pl->use_f3 && !want_stamps && (!(kp.flags & 0x7f00) || dev_env().f3_debug);
+  const bool no_spec = dev_env().no_spec;       // A/B: the two-pass pipeline with k_frames3
   if (f3 && !no_spec && pl->nblocks > 0) {
     // the samples are read once: frames before the trim decision (which the same pass feeds), then the few frames a cut touches
     const int max_items = n * kF3ItemsPerClip;
@@ -482,8 +514,8 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
   const ClipInfo* h_info = (const ClipInfo*)((char*)pl->h_pin + ((stats_bytes + 15) & ~(size_t)15));
   HIP_TRY(hipMemcpyAsync(h_stats, pl->stats.p, stats_bytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync((void*)h_info, d_info, info_bytes, hipMemcpyDeviceToHost, s));
-  if (out_frames && frames_floats)
-    HIP_TRY(hipMemcpyAsync(out_frames, d_frames, frames_floats * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (out_frames && f_hi > f_lo)
+    HIP_TRY(hipMemcpyAsync(out_frames + f_lo, d_frames, (size_t)(f_hi - f_lo) * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (pl->timing) {
     for (int k = 0; k < AFX_K_COUNT; ++k) {
@@ -517,7 +549,7 @@ extern "C" int afx_extract_batch(afx_plan* pl, const void* samples, int sample_f
   (void)hipGetLastError();      // a stale error of an unrelated earlier call must not be blamed on this one
   HIP_TRY(hipSetDevice(pl->device));
   const int nstat = 4 * pl->p.n_mfcc + 3;
-  const int kChunk = 32768;   // gridDim.y limit is 65535
+  const int kChunk = dev_env().chunk_clips;   // 32768: gridDim.y limit is 65535
   for (int c0 = 0; c0 < n_clips; c0 += kChunk) {
     const int n = std::min(kChunk, n_clips - c0);
     int rc = extract_chunk(pl, samples, sample_fmt, mem_kind, offsets + c0, lengths + c0, n, flags,
@@ -576,7 +608,7 @@ static int f0_setup(afx_plan* pl, double fmin, double fmax) {
       (rc = up(ht.bexp, &pl->f0_dt.bexp)) != AFX_OK || (rc = up(ht.lt, &pl->f0_dt.lt)) != AFX_OK || (rc = up(ht.ltw, &pl->f0_dt.ltw)) != AFX_OK ||
       (rc = up(ht.freqs, &pl->f0_dt.freqs)) != AFX_OK)
     return rc;
-  if (const char* dbg = getenv("AFX_F0_DEBUG")) ht.p.debug = atoi(dbg);
+  if (dev_env().f0_debug) ht.p.debug = dev_env().f0_debug;
   pl->f0_ht = ht;
   pl->f0_fmin = fmin; pl->f0_fmax = fmax;
   pl->f0_ready = true;
@@ -607,14 +639,24 @@ static int f0_chunk(afx_plan* pl, const void* d_samples, int fmt, const int64_t*
   if ((rc = ensure(pl->f0_lu, (size_t)frames * sizeof(double))) != AFX_OK) return rc;
   if ((rc = ensure(pl->f0_states, (size_t)frames * sizeof(uint16_t))) != AFX_OK) return rc;
   if ((rc = ensure(pl->f0_stats, (size_t)n * 4 * sizeof(double))) != AFX_OK) return rc;
+  // per-frame f0 of this chunk: [o_lo, o_hi) of the caller's buffer, device copy rebased to it (see extract_chunk)
   double* d_f0 = nullptr;
-  size_t f0_count = 0;
+  int64_t o_lo = 0, o_hi = 0;
+  std::vector<int64_t> rebased;
   if (out_f0) {
     if (!f0_offsets) { set_error("out_f0 given without f0_offsets"); return AFX_ERR_INVALID; }
-    for (int i = 0; i < n; ++i) f0_count = std::max<size_t>(f0_count, (size_t)f0_offsets[i] + (size_t)pl->h_clips[i].tmax);
-    if ((rc = ensure(pl->f0_out, f0_count * sizeof(double))) != AFX_OK) return rc;
+    o_lo = INT64_MAX;
+    for (int i = 0; i < n; ++i) {
+      if (f0_offsets[i] < 0) { set_error("negative f0 offset"); return AFX_ERR_INVALID; }
+      o_lo = std::min(o_lo, f0_offsets[i]);
+      o_hi = std::max(o_hi, f0_offsets[i] + (int64_t)pl->h_clips[i].tmax);
+    }
+    rebased.resize(n);
+    for (int i = 0; i < n; ++i) rebased[i] = f0_offsets[i] - o_lo;
+    if ((rc = ensure(pl->f0_out, (size_t)(o_hi - o_lo) * sizeof(double))) != AFX_OK) return rc;
     if ((rc = ensure(pl->f0_offs, n * sizeof(int64_t))) != AFX_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(pl->f0_offs.p, f0_offsets, n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(pl->f0_offs.p, rebased.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(pl->f0_out.p, 0xff, (size_t)(o_hi - o_lo) * sizeof(double), s));     // NaN wherever no clip writes
     d_f0 = (double*)pl->f0_out.p;
   }
   KParams kp = pl->kp;
@@ -636,9 +678,9 @@ static int f0_chunk(afx_plan* pl, const void* d_samples, int fmt, const int64_t*
   std::vector<ClipInfo> h_info(n);
   HIP_TRY(hipMemcpyAsync(out_stats, pl->f0_stats.p, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(h_info.data(), d_info, n * sizeof(ClipInfo), hipMemcpyDeviceToHost, s));
-  if (out_f0 && f0_count) HIP_TRY(hipMemcpyAsync(out_f0, d_f0, f0_count * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (out_f0 && o_hi > o_lo) HIP_TRY(hipMemcpyAsync(out_f0 + o_lo, d_f0, (size_t)(o_hi - o_lo) * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (const char* dump = getenv("AFX_F0_DUMP")) {                       // diagnostics: the sparse observation columns
+  if (const char* dump = dev_env().f0_dump) {                       // diagnostics: the sparse observation columns
     std::vector<int32_t> cnt(frames); std::vector<double> vp(frames), pr((size_t)frames * fp.cap);
     std::vector<int16_t> bn((size_t)frames * fp.cap);
     HIP_TRY(hipMemcpy(cnt.data(), pl->f0_cnt.p, frames * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -683,12 +725,12 @@ extern "C" int afx_f0_batch(afx_plan* pl, const void* samples, int sample_fmt, i
   }
   // the stage keeps ~14 KB of workspace per frame (Viterbi value columns 9.6 KB, candidates and their logs, energies): bound it
   // per chunk (18 GB; a chunk should still hold several clips per CU so that every CU runs two Viterbi workgroups)
-  const int64_t kMaxFrames = 1280 * 1024;
+  const int64_t kMaxFrames = dev_env().f0_chunk_frames;
   int c0 = 0;
   while (c0 < n_clips) {
     int n = 0;
     int64_t fr = 0;
-    while (c0 + n < n_clips && n < 32768) {
+    while (c0 + n < n_clips && n < dev_env().chunk_clips) {
       const int64_t t = 1 + lengths[c0 + n] / pl->p.hop + kFramesPerBlock;
       if (n > 0 && fr + t > kMaxFrames) break;
       fr += t; ++n;

@@ -91,80 +91,127 @@ def _pack(clips: List[np.ndarray], dtype) -> Tuple[np.ndarray, np.ndarray, np.nd
 LAST_TIMING: Dict[str, Any] = {}     # seconds per phase of the last process_files call (developer aid)
 WORKERS_PER_GPU = 3     # sub-batches in flight per GPU (own context / stream / thread): copies, the bandwidth-bound
                         # kernels and the host round trip of one hide under the frame kernel of another
+DECODE_THREADS_PER_GPU = 16
+
+
+def _windows(sizes: Sequence[int], idxs: Sequence[int], budget: int) -> List[List[int]]:
+    """Cuts a lane's files (in order) into windows whose estimated sample count stays under ``budget``;
+    a single file larger than the budget is a window of its own."""
+    out: List[List[int]] = []
+    cur: List[int] = []
+    tot = 0
+    for i in idxs:
+        sz = int(sizes[i])
+        if cur and tot + sz > budget:
+            out.append(cur)
+            cur, tot = [], 0
+        cur.append(i)
+        tot += sz
+    if cur:
+        out.append(cur)
+    return out
 
 
 def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 1024 * 1024,
                   workers_per_gpu: int = WORKERS_PER_GPU) -> List[Dict[str, Any]]:
-    """Decode -> shard over GPUs (and over a few workers per GPU) -> fused extract -> dicts in input (glob) order."""
+    """Shard over GPUs (and over a few workers per GPU) -> per worker a pipeline of bounded windows:
+    decode window k + 1 on the shared host pool while window k is packed, uploaded and extracted ->
+    dicts in input (glob) order.  Host memory holds at most two windows per worker, not the directory.
+
+    Error behaviour is the reference's (feature_extractor.py:229-235): a file that cannot be loaded, a clip the
+    kernels reject, or a device-level failure while its window is processed is logged and left out; the batch goes on."""
+    import os
     log = extractor.logger
     n = len(files)
     if n == 0:
         return []
     devices = extractor._devices()
     t_start = time.perf_counter()
-    decoded: List[Any] = [None] * n
     errors: List[Any] = [None] * n
+    K = extractor.n_mfcc
+    stats = np.zeros((n, 4 * K + 3), np.float32)
+    status = np.full(n, -1, np.int32)          # -1: not extracted (yet)
+    nframes = np.zeros(n, np.int32)
+    f0s = np.zeros((n, 4), np.float64)
+    f0_done = np.zeros(n, bool)
+    lanes = [(d, w) for d in devices for w in range(max(1, int(workers_per_gpu)))]
+    if n < 4 * len(lanes):                             # small jobs: one worker per GPU
+        lanes = [(d, 0) for d in devices]
+    # shard by file size (a proxy for clip length that needs no decode): longest-processing-time-first
+    def fsize(f):
+        try:
+            return max(1, os.path.getsize(str(f)) // 2)
+        except OSError:
+            return 1
+    sizes = [fsize(f) for f in files]
+    parts = lpt_partition(sizes, len(lanes))
+    flags = _native.FLAG_PREEMPH | _native.FLAG_TRIM
+    pool = ThreadPoolExecutor(max(1, min(os.cpu_count() or 1, DECODE_THREADS_PER_GPU * len(devices), n)))
+    phase = {"decode_wait": 0.0, "device": 0.0}
+    phase_lock = threading.Lock()
 
     def dec(i):
         try:
-            decoded[i] = _decode(str(files[i]), extractor.sr)
+            return _decode(str(files[i]), extractor.sr)
         except Exception as e:          # load_audio: log + the file is dropped
             log.error(f"載入音頻文件失敗: {str(e)}")
             errors[i] = e
-
-    with ThreadPoolExecutor(max(1, min(16, n))) as ex:
-        list(ex.map(dec, range(n)))
-
-    t_decoded = time.perf_counter()
-    ok = [i for i in range(n) if decoded[i] is not None]
-    K = extractor.n_mfcc
-    stats = np.zeros((n, 4 * K + 3), np.float32)
-    status = np.full(n, -1, np.int32)
-    nframes = np.zeros(n, np.int32)
-    f0s = np.zeros((n, 4), np.float64)
-    want_f0 = getattr(extractor, "_f0_on_gpu", lambda: False)()
-    lanes = [(d, w) for d in devices for w in range(max(1, int(workers_per_gpu)))]
-    if len(ok) < 4 * len(lanes):                       # small jobs: one worker per GPU
-        lanes = [(d, 0) for d in devices]
-    parts = lpt_partition([decoded[i][1].size for i in ok], len(lanes))
-    flags = _native.FLAG_PREEMPH | _native.FLAG_TRIM
+            return None
 
     def worker(lane, idxs):
-        try:
-            plan = extractor._plan(lane[0], lane[1])
-            for kind, fmt, dt in (("s16", _native.FMT_S16, np.int16), ("f32", _native.FMT_F32, np.float32)):
-                sel = [ok[j] for j in idxs if decoded[ok[j]][0] == kind]
-                pos = 0
-                while pos < len(sel):
-                    tot, end = 0, pos
-                    while end < len(sel) and (end == pos or tot + decoded[sel[end]][1].size <= max_batch_samples):
-                        tot += decoded[sel[end]][1].size
-                        end += 1
-                    chunk = sel[pos:end]
-                    buf, offs, lens = _pack([decoded[i][1] for i in chunk], dt)
-                    dbuf = _native.DeviceBuffer(plan.ctx, max(buf.nbytes, 16))       # one PCIe copy for both passes
-                    try:
-                        dbuf.upload(buf)
-                        out = plan.extract_batch(dbuf, offs, lens, flags=flags, fmt=fmt)
-                        stats[chunk] = out["stats"]
-                        status[chunk] = out["status"]
-                        nframes[chunk] = out["nframes"]
-                        if want_f0:
+        wins = _windows(sizes, idxs, max_batch_samples)
+        pending = [pool.submit(dec, i) for i in wins[0]] if wins else []
+        plan = None
+        for k, win in enumerate(wins):
+            t0 = time.perf_counter()
+            decoded = [f.result() for f in pending]
+            # next window decodes while this one is on the device
+            pending = [pool.submit(dec, i) for i in wins[k + 1]] if k + 1 < len(wins) else []
+            t1 = time.perf_counter()
+            cur: List[int] = []
+            try:
+                if plan is None:
+                    plan = extractor._plan(lane[0], lane[1])
+                for kind, fmt, dt in (("s16", _native.FMT_S16, np.int16), ("f32", _native.FMT_F32, np.float32)):
+                    sel = [(i, d[1]) for i, d in zip(win, decoded) if d is not None and d[0] == kind]
+                    pos = 0
+                    while pos < len(sel):          # a window may still exceed the budget (sizes were estimates)
+                        tot, end = 0, pos
+                        while end < len(sel) and (end == pos or tot + sel[end][1].size <= max_batch_samples):
+                            tot += sel[end][1].size
+                            end += 1
+                        cur = [i for i, _ in sel[pos:end]]
+                        buf, offs, lens = _pack([y for _, y in sel[pos:end]], dt)
+                        dbuf = plan.device_buffer(max(buf.nbytes, 16))       # one PCIe copy for both passes
+                        try:
+                            dbuf.upload(buf)
+                            out = plan.extract_batch(dbuf, offs, lens, flags=flags, fmt=fmt)
                             f0 = plan.f0_batch(dbuf, offs, lens, extractor.f0_min, extractor.f0_max, flags=flags, fmt=fmt)
-                            f0s[chunk] = f0["stats"]
-                    finally:
-                        dbuf.free()
-                    pos = end
-        except Exception as e:          # a device-level failure drops that shard's files
-            for j in idxs:
-                if errors[ok[j]] is None and status[ok[j]] < 0:
-                    errors[ok[j]] = e
+                            stats[cur] = out["stats"]
+                            nframes[cur] = out["nframes"]
+                            f0s[cur] = f0["stats"]
+                            f0_done[cur] = True
+                            status[cur] = out["status"]          # last: a file counts only with both passes done
+                        finally:
+                            dbuf.free()
+                        cur = []
+                        pos = end
+            except Exception as e:          # a device-level failure drops the files of the sub-batch it hit, and the
+                for i in win:               # rest of this window; later windows are still attempted
+                    if errors[i] is None and not (status[i] >= 0 and f0_done[i]):
+                        errors[i] = e
+                        status[i] = -1
+            del decoded
+            with phase_lock:
+                phase["decode_wait"] += t1 - t0
+                phase["device"] += time.perf_counter() - t1
 
     threads = [threading.Thread(target=worker, args=(ln, p)) for ln, p in zip(lanes, parts) if p]
     for t in threads:
         t.start()
     for t in threads:
         t.join()
+    pool.shutdown()
 
     t_gpu = time.perf_counter()
     results: List[Dict[str, Any]] = []
@@ -179,8 +226,8 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
             log.error(f"處理文件 {name} 失敗: {str(err)}")
             continue
         mfcc, energy = extractor._stats_to_dicts(stats[i])
-        f0d = extractor._f0_to_dict(f0s[i]) if want_f0 else extractor.extract_f0(decoded[i][1])
-        results.append({"file_path": str(f), **f0d, **mfcc, **energy})
+        results.append({"file_path": str(f), **extractor._f0_to_dict(f0s[i]), **mfcc, **energy})
         log.info(f"成功處理文件: {name}")
-    LAST_TIMING.update(decode=t_decoded - t_start, device=t_gpu - t_decoded, dicts=time.perf_counter() - t_gpu, files=n)
+    LAST_TIMING.update(pipeline=t_gpu - t_start, decode_wait=phase["decode_wait"], device=phase["device"],
+                       dicts=time.perf_counter() - t_gpu, files=n, workers=len(threads))
     return results

@@ -43,14 +43,22 @@ def voiced_tone(freq, seconds, vib=0.0, seed=0):
     return y.astype(np.float32)
 
 
-def check_clip(f0_gpu, stats_gpu, y_processed, tag):
+NON_IDENTICAL = {}      # tag -> (frames that differ from the oracle's track, frames): printed by the last test of the module
+
+
+def check_clip(f0_gpu, stats_gpu, y_processed, tag, max_diff=0):
+    """max_diff: frames allowed to differ from the oracle's decoded track.  0 for single-source clips (the decoded
+    state sequence is the oracle's, frame for frame); the random-mixture test passes its own bound (DESIGN.md 7:
+    the 0-versus-2e-19 unvoiced observation of a strongly voiced frame depends on BLAS's summation order)."""
     f0_ref, voiced_ref, _ = P.pyin(y_processed, sr=SR, frame_length=1024, hop_length=256)
     assert f0_gpu.shape == f0_ref.shape, tag
     same = (np.isnan(f0_gpu) == np.isnan(f0_ref))
     v = ~np.isnan(f0_ref) & ~np.isnan(f0_gpu)
     same[v] &= np.abs(f0_gpu[v] - f0_ref[v]) <= 1e-9 * f0_ref[v]
-    # the decoded path must be the oracle's; allow isolated frames for near-ties in float64 log/argmax
-    assert same.mean() >= 0.99, (tag, same.mean(), np.flatnonzero(~same)[:10])
+    n_diff = int((~same).sum())
+    NON_IDENTICAL[tag] = (n_diff, int(same.size))
+    print(f"[f0] {tag}: {n_diff} of {same.size} frames differ from the oracle's track")
+    assert n_diff <= max_diff, (tag, n_diff, same.size, np.flatnonzero(~same)[:10])
     ref = P.extract_f0(y_processed, sr=SR, frame_length=1024, hop_length=256)
     if same.all():
         np.testing.assert_allclose(stats_gpu, [ref["f0_mean"], ref["f0_std"], ref["f0_missing_rate"], ref["f0_quality"]],
@@ -116,9 +124,12 @@ def test_f0_other_frame_sizes(sr, n_fft, hop):
             same = np.isnan(f0) == np.isnan(ref)
             v = ~np.isnan(f0) & ~np.isnan(ref)
             same[v] &= np.abs(f0[v] - ref[v]) <= 1e-9 * ref[v]
-            assert same.mean() >= 0.99, (sr, i, same.mean())
+            NON_IDENTICAL[f"{sr}/{n_fft} clip{i}"] = (int((~same).sum()), int(same.size))
+            print(f"[f0] {sr}/{n_fft} clip{i}: {int((~same).sum())} of {same.size} frames differ from the oracle's track")
+            assert same.all(), (sr, i, same.mean(), np.flatnonzero(~same)[:10])
             r = P.extract_f0(c, sr=sr, frame_length=n_fft, hop_length=hop)
-            assert abs(out["stats"][i][0] - r["f0_mean"]) <= 5e-3 * max(r["f0_mean"], 1.0)
+            np.testing.assert_allclose(out["stats"][i], [r["f0_mean"], r["f0_std"], r["f0_missing_rate"], r["f0_quality"]],
+                                       rtol=1e-10, atol=1e-12)
     finally:
         pl.close()
         ctx.close()
@@ -191,8 +202,12 @@ def test_f0_random_mixtures(plan):
         v = ~np.isnan(f0[i]) & ~np.isnan(ref)
         same[v] &= np.abs(f0[i][v] - ref[v]) <= 1e-9 * ref[v]
         fracs.append(same.mean())
+        NON_IDENTICAL[f"mixture{i}"] = (int((~same).sum()), int(same.size))
+        print(f"[f0] mixture{i}: {int((~same).sum())} of {same.size} frames differ from the oracle's track")
         assert same.mean() >= 0.9, (i, same.mean(), np.flatnonzero(~same)[:12])
     assert np.mean(fracs) >= 0.98 and np.median(fracs) == 1.0, fracs
+    # round 1 measured 6 frames of one clip; a drift from that shows here
+    assert sum(NON_IDENTICAL[f"mixture{i}"][0] for i in range(8)) <= 12, {k: v for k, v in NON_IDENTICAL.items() if k.startswith("mixture")}
 
 
 def test_f0_batch_is_clipwise_independent(plan):
@@ -217,3 +232,14 @@ def test_f0_batch_is_clipwise_independent(plan):
     np.testing.assert_array_equal(solo["stats"][0], out["stats"][first[5]])
     assert np.isfinite(out["stats"]).all() and (out["stats"][:, 2] >= 0).all() and (out["stats"][:, 2] <= 1).all()
     np.testing.assert_allclose(out["stats"][:, 2] + out["stats"][:, 3], 1.0, atol=1e-15)
+
+
+def test_zz_report_non_identical_frames():
+    """Not a check of its own: prints, per clip tested above, how many frames differed from the oracle's decoded
+    track (run with -s, or read the assertion message of a failing bound), so that a drift from 0 is visible."""
+    tot = sum(v[0] for v in NON_IDENTICAL.values())
+    frames = sum(v[1] for v in NON_IDENTICAL.values())
+    print(f"[f0] non-identical frames: {tot} of {frames} over {len(NON_IDENTICAL)} clips; per clip: "
+          + ", ".join(f"{k}={v[0]}" for k, v in NON_IDENTICAL.items() if v[0]))
+    single = {k: v for k, v in NON_IDENTICAL.items() if not k.startswith("mixture")}
+    assert sum(v[0] for v in single.values()) == 0, single

@@ -84,3 +84,147 @@ def test_two_rank_gloo_file_shard(tmp_path):
         st = R.extract_stats(make_clip(i, 8000, 0.5), sr=8000, frame_length=256, hop_length=64, n_mfcc=5)
         ref.append(np.concatenate([st["mfcc_mean"], st["mfcc_std"], [st["energy_mean"]]]).astype(np.float32))
     np.testing.assert_array_equal(got, np.stack(ref))      # same rows, global order, bit for bit
+
+
+# ---------------------------------------------------------------------------------------------------
+# The in-process multi-GPU path (parallel.process_files) on 8 fake devices: sharding, ordering, per-file
+# and per-device failure behaviour (the reference drops a failing file and goes on,
+# audio_feature_extraction_toolkit/core/feature_extractor.py:229-235).  No GPU, no libafx.
+# ---------------------------------------------------------------------------------------------------
+class _FakeBuf:
+    def __init__(self, log):
+        self.log = log
+        self.data = None
+
+    def upload(self, arr):
+        self.data = np.array(arr, copy=True)
+
+    def free(self):
+        self.log.append("free")
+
+
+class _FakePlan:
+    """Stands in for _native.Plan: 'features' are functions of the samples, so the test can check which clip went where."""
+
+    def __init__(self, device, lane, calls, fail_extract=False, fail_f0=False):
+        self.device, self.lane, self.calls = device, lane, calls
+        self.fail_extract, self.fail_f0 = fail_extract, fail_f0
+        self.buflog = []
+
+    def device_buffer(self, nbytes):
+        return _FakeBuf(self.buflog)
+
+    def extract_batch(self, dbuf, offs, lens, flags=0, fmt=0):
+        if self.fail_extract:
+            raise RuntimeError(f"device {self.device} fell over")
+        n = len(offs)
+        stats = np.zeros((n, 4 * 13 + 3), np.float32)
+        status = np.zeros(n, np.int32)
+        nfr = np.zeros(n, np.int32)
+        for i in range(n):
+            y = dbuf.data[offs[i]: offs[i] + lens[i]].astype(np.float64)
+            if fmt == 1:
+                y = y / 32768.0
+            stats[i, 0] = y.sum()
+            stats[i, 4 * 13] = np.sqrt((y * y).mean())
+            nfr[i] = 1 + lens[i] // 256
+            if lens[i] < 9 * 256:
+                status[i] = 1                  # CLIP_TOO_SHORT
+        self.calls.append((self.device, self.lane, n))
+        return {"stats": stats, "status": status, "nframes": nfr}
+
+    def f0_batch(self, dbuf, offs, lens, fmin, fmax, flags=0, fmt=0):
+        if self.fail_f0:
+            raise RuntimeError(f"pYIN workspace on device {self.device}")
+        out = np.zeros((len(offs), 4))
+        out[:, 0] = 100.0 + self.device
+        return {"stats": out, "status": np.zeros(len(offs), np.int32)}
+
+
+def _fake_extractor(n_dev, calls, bad_extract=(), bad_f0=()):
+    import logging
+    from audio_feature_extraction_amd.core.feature_extractor import AudioFeatureExtractor
+    ex = AudioFeatureExtractor.__new__(AudioFeatureExtractor)
+    ex.sr, ex.n_mfcc, ex.f0_min, ex.f0_max = 8000, 13, 65.4, 2093.0
+    ex.logger = logging.getLogger("fake")
+    plans = {}
+
+    def _plan(device=None, lane=0):
+        key = (device, lane)
+        if key not in plans:
+            plans[key] = _FakePlan(device, lane, calls, fail_extract=device in bad_extract, fail_f0=device in bad_f0)
+        return plans[key]
+    ex._devices = lambda: list(range(n_dev))
+    ex._plan = _plan
+    return ex, plans
+
+
+def _write_clips(tmp_path, n, short=()):
+    from audio_feature_extraction_amd import wavio
+    rng = np.random.default_rng(5)
+    files, sums = [], []
+    for i in range(n):
+        m = 200 if i in short else int(rng.integers(3000, 9000))
+        y = (rng.standard_normal(m) * 0.1).astype(np.float32)
+        p = tmp_path / f"c{i:03d}.wav"
+        wavio.write_wav_pcm16(str(p), y, 8000)
+        q = np.clip(np.round(y * 32768.0), -32768, 32767) / 32768.0
+        files.append(p)
+        sums.append(q.sum())
+    return files, np.array(sums)
+
+
+def test_process_files_on_eight_fake_devices(tmp_path):
+    from audio_feature_extraction_amd import parallel
+    files, sums = _write_clips(tmp_path, 70, short=(11, 40))
+    (tmp_path / "c012.wav").write_bytes(b"not a wav file")          # a file that cannot be decoded
+    calls = []
+    ex, plans = _fake_extractor(8, calls)
+    res = parallel.process_files(ex, files)
+    got = [os.path.basename(r["file_path"]) for r in res]
+    want = [f.name for i, f in enumerate(files) if i not in (11, 12, 40)]
+    assert got == want                                               # input order, failing files left out
+    for r in res:
+        i = int(os.path.basename(r["file_path"])[1:4])
+        assert abs(r["mfcc_mean"][0] - sums[i]) < 1e-3 * max(1.0, abs(sums[i]))
+        assert set(r) >= {"file_path", "f0_mean", "mfcc_mean", "energy_mean"} and isinstance(r["mfcc_mean"], list)
+    used = {(d, l) for d, l, _ in calls}
+    assert {d for d, _ in used} == set(range(8))                     # every device got work
+    per_dev = {d: sum(n for dd, _, n in calls if dd == d) for d in range(8)}
+    assert max(per_dev.values()) - min(per_dev.values()) <= 4        # balanced by size
+    assert all(p.buflog for p in plans.values() if any(c[0] == p.device and c[1] == p.lane for c in calls))
+    assert parallel.LAST_TIMING["files"] == 70
+
+
+def test_a_failing_device_drops_only_its_shard(tmp_path):
+    from audio_feature_extraction_amd import parallel
+    files, _ = _write_clips(tmp_path, 64)
+    calls = []
+    ex, _ = _fake_extractor(8, calls, bad_extract=(3,))
+    res = parallel.process_files(ex, files)
+    assert 0 < len(res) < 64 and len(res) >= 64 - 12                 # one device's share is gone, the rest is there
+    order = [os.path.basename(r["file_path"]) for r in res]
+    assert order == sorted(order)
+    assert all(r["f0_mean"] != 103.0 for r in res)
+
+
+def test_f0_failure_drops_the_files_instead_of_reporting_zero_f0(tmp_path):
+    """extract_batch had already filled status when f0_batch raised, and the files came back as
+    successes with an all-zero f0 row.  A file counts only when both passes are done."""
+    from audio_feature_extraction_amd import parallel
+    files, _ = _write_clips(tmp_path, 40)
+    calls = []
+    ex, _ = _fake_extractor(4, calls, bad_f0=(1,))
+    res = parallel.process_files(ex, files)
+    assert 0 < len(res) < 40
+    assert all(r["f0_mean"] in (100.0, 102.0, 103.0) for r in res)   # nothing from device 1, no zero rows
+
+
+def test_windows_bound_host_memory(tmp_path):
+    from audio_feature_extraction_amd import parallel
+    assert parallel._windows([5, 5, 5, 20, 1], [0, 1, 2, 3, 4], 10) == [[0, 1], [2], [3], [4]]
+    files, sums = _write_clips(tmp_path, 30)
+    calls = []
+    ex, _ = _fake_extractor(2, calls)
+    res = parallel.process_files(ex, files, max_batch_samples=12000, workers_per_gpu=1)   # forces several windows per worker
+    assert len(res) == 30 and len(calls) > 4
