@@ -27,7 +27,7 @@ SYMBOLS = (
     "afx_version", "afx_device_count", "afx_last_error", "afx_init", "afx_destroy",
     "afx_malloc", "afx_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
     "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables", "afx_build_mel_schedule",
-    "afx_extract_batch", "afx_f0_batch", "afx_zcr_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings",
+    "afx_extract_batch", "afx_f0_batch", "afx_zcr_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings", "afx_plan_get_intervals",
 )
 
 
@@ -85,6 +85,7 @@ def lib() -> C.CDLL:
         L.afx_preprocess.argtypes = [vp, vp, C.c_int64, vp, i64p, i64p, i32p]
         L.afx_plan_set_timing.argtypes = [vp, i32]
         L.afx_plan_get_timings.argtypes = [vp, vp, vp, i32]
+        L.afx_plan_get_intervals.argtypes = [vp, i32, vp, vp, i32, i32p]
         _lib = L
     return _lib
 
@@ -233,6 +234,15 @@ class Plan:
         n = np.zeros(len(K_NAMES), np.int32)
         _check(lib().afx_plan_get_timings(self.handle, ms.ctypes.data, n.ctypes.data, 1 if reset else 0), "afx_plan_get_timings")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(K_NAMES)}
+
+    def intervals(self, kernel: str = "frames", cap: int = 65536) -> np.ndarray:
+        """[n, 2] (start, end) ms of the kernel's launches since the last timings(reset=True), on the device-wide clock."""
+        st, en = np.zeros(cap), np.zeros(cap)
+        cnt = C.c_int32()
+        _check(lib().afx_plan_get_intervals(self.handle, K_NAMES.index(kernel), st.ctypes.data, en.ctypes.data, cap, C.byref(cnt)),
+               "afx_plan_get_intervals")
+        n = min(int(cnt.value), cap)
+        return np.stack([st[:n], en[:n]], axis=1)
 
     def extract_batch(self, samples, offsets, lengths, flags=FLAG_PREEMPH | FLAG_TRIM,
                       fmt=FMT_F32, want_frames: bool = False, out=None):

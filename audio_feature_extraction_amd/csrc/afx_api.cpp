@@ -70,6 +70,7 @@ struct afx_plan {
   bool ev_ready = false;
   double ms_sum[AFX_K_COUNT] = {};
   int32_t launches[AFX_K_COUNT] = {};
+  std::vector<std::pair<double, double>> spans[AFX_K_COUNT];   // (start, end) ms on the device's common clock, newest kMaxSpans
   int n_cu = 256;
 };
 
@@ -295,9 +296,31 @@ extern "C" void afx_plan_destroy(afx_plan* pl) {
   delete pl;
 }
 
+// One reference event per device, recorded once: launch intervals of every plan (= every stream) on that device are
+// reported against it, so that a caller can merge the intervals of streams that run side by side.
+static std::mutex g_ref_mu;
+static hipEvent_t g_ref[64] = {};
+static bool g_ref_set[64] = {};
+constexpr size_t kMaxSpans = 1 << 16;
+
+static int device_ref(afx_plan* pl, hipEvent_t* out) {
+  std::lock_guard<std::mutex> lk(g_ref_mu);
+  const int d = pl->device;
+  if (d < 0 || d >= 64) { set_error("device index out of range for timing"); return AFX_ERR_INVALID; }
+  if (!g_ref_set[d]) {
+    HIP_TRY(hipEventCreate(&g_ref[d]));
+    HIP_TRY(hipEventRecord(g_ref[d], pl->ctx->stream));
+    HIP_TRY(hipEventSynchronize(g_ref[d]));
+    g_ref_set[d] = true;
+  }
+  *out = g_ref[d];
+  return AFX_OK;
+}
+
 extern "C" int afx_plan_set_timing(afx_plan* pl, int enable) {
   if (!pl) { set_error("afx_plan_set_timing: null plan"); return AFX_ERR_INVALID; }
   HIP_TRY(hipSetDevice(pl->device));
+  if (enable) { hipEvent_t r; int rc = device_ref(pl, &r); if (rc != AFX_OK) return rc; }
   if (enable && !pl->ev_ready) {
     for (int k = 0; k < AFX_K_COUNT; ++k) { HIP_TRY(hipEventCreate(&pl->ev[k][0])); HIP_TRY(hipEventCreate(&pl->ev[k][1])); }
     pl->ev_ready = true;
@@ -311,8 +334,20 @@ extern "C" int afx_plan_get_timings(afx_plan* pl, float* ms, int32_t* launches, 
   for (int k = 0; k < AFX_K_COUNT; ++k) {
     if (ms) ms[k] = (float)pl->ms_sum[k];
     if (launches) launches[k] = pl->launches[k];
-    if (reset) { pl->ms_sum[k] = 0.0; pl->launches[k] = 0; }
+    if (reset) { pl->ms_sum[k] = 0.0; pl->launches[k] = 0; pl->spans[k].clear(); }
   }
+  return AFX_OK;
+}
+
+extern "C" int afx_plan_get_intervals(afx_plan* pl, int slot, double* start_ms, double* end_ms, int cap, int32_t* count) {
+  if (!pl || slot < 0 || slot >= AFX_K_COUNT || cap < 0 || !count) { set_error("afx_plan_get_intervals: invalid argument"); return AFX_ERR_INVALID; }
+  const auto& v = pl->spans[slot];
+  const int n = (int)std::min<size_t>(v.size(), (size_t)cap);
+  for (int i = 0; i < n; ++i) {
+    if (start_ms) start_ms[i] = v[v.size() - n + i].first;
+    if (end_ms) end_ms[i] = v[v.size() - n + i].second;
+  }
+  *count = (int32_t)v.size();
   return AFX_OK;
 }
 
@@ -521,8 +556,15 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
     for (int k = 0; k < AFX_K_COUNT; ++k) {
       if (pl->nblocks == 0 && (k == AFX_K_FRAMES || k == AFX_K_DCT)) continue;
       if (pl->launches[k] == 0) continue;
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, pl->ev[k][0], pl->ev[k][1]) == hipSuccess) pl->ms_sum[k] += ms;
+      float ms = 0.f, t0 = 0.f;
+      if (hipEventElapsedTime(&ms, pl->ev[k][0], pl->ev[k][1]) == hipSuccess) {
+        pl->ms_sum[k] += ms;
+        hipEvent_t ref;
+        if (device_ref(pl, &ref) == AFX_OK && hipEventElapsedTime(&t0, ref, pl->ev[k][0]) == hipSuccess) {
+          if (pl->spans[k].size() >= kMaxSpans) pl->spans[k].erase(pl->spans[k].begin(), pl->spans[k].begin() + kMaxSpans / 2);
+          pl->spans[k].emplace_back((double)t0, (double)t0 + (double)ms);
+        }
+      }
     }
   }
   std::memcpy(out_stats, h_stats, stats_bytes);

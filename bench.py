@@ -1,32 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- MFCC frames/sec of the fused HIP hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {2,3,5}]
 
-Workload (BASELINE.json configs[1]; configs[3] when N > 1): per GPU, 1000 synthetic
-10 s clips @22050 Hz, frame_length=1024, hop_length=256, n_mfcc=13 (SURVEY.md 8(d)
-generator), already resident in HBM when the timed region starts.  One "step" = one
-pass of preprocess_audio -> extract_mfcc + extract_energy over that batch
-(trim, fused frame kernel, DCT, statistics; 4*13+3 floats per clip copied back).
-Scaling is weak: every rank owns its own 1000 clips, no data-path collective; the only
-torch.distributed traffic is the timing barrier and the max-over-ranks reduction.
-Within a rank the clips are cut into --streams (default 3) runs that are in flight side by
-side, one context / HIP stream / host thread each -- how batch_process drives a GPU: one
-run's bandwidth-bound kernels and host round trip hide under another's frame kernel.  A step
-is still one pass over all of the rank's clips; K steps = K passes by every run.
+Workload (default BASELINE.json configs[1]; configs[3] = the same per GPU when N > 1): per GPU, 1000 synthetic
+10 s clips @22050 Hz, frame_length=1024, hop_length=256, n_mfcc=13 (SURVEY.md 8(d) generator), already resident in
+HBM when the timed region starts.  --config 3 / 5 run BASELINE.json configs[2] / configs[4] (16 kHz 512/128/40 and
+44.1 kHz 2048/512/20) the same way; they are parity cases with their own roofline lines, not the headline metric.
+One "step" = one pass of preprocess_audio -> extract_mfcc + extract_energy over that batch (frame kernel before the trim
+decision, trim decision, redo launch, DCT, statistics; 4*n_mfcc+3 floats per clip copied back).
+Scaling is weak: every rank owns its own 1000 clips, no data-path collective; the only torch.distributed traffic is
+the timing barrier and the max-over-ranks reduction.  `python bench.py --gpus N` without a launcher starts the N ranks
+itself (children, before anything touches the GPU).
+Within a rank the clips are cut into --streams (default 3) runs that are in flight side by side, one context / HIP
+stream / host thread each -- how batch_process drives a GPU.  A step is still one pass over all of the rank's clips.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     -- the frame kernel k_frames2 (dominant): algorithmic bytes = 4*hop per frame (each
-                  input sample read once) / average launch duration from HIP events
-                  recorded on the kernel's own stream inside the timed region;
-  cpu_baseline -- the numpy/scipy oracle (a port of the reference's librosa path) timed
-                  on this box's host cores over a bounded sample of the same workload.
+  roofline     -- the frame kernel (dominant): algorithmic bytes = 4*hop per frame (each input sample read once) /
+                  average launch duration.  Durations come from HIP events recorded on the kernel's own stream around
+                  every launch of the timed region; with several streams in flight the launches overlap, so the time
+                  the GPU spends in the kernel is the UNION of their intervals (common device clock): avg_launch_ms =
+                  union / launches, and kernel time per step <= ms_per_step by construction.  `exclusive` is the same
+                  kernel over the whole batch on one stream (what profiles/r02_*_kernel_stats.csv shows);
+                  `fp32` the secondary vector-FLOP roofline;
+  cpu_baseline -- the numpy/scipy oracle (a port of the reference's librosa path) timed on this box's host cores over a
+                  bounded sample of the same workload: one core, and a pool over every core this process may use.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,41 +39,78 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SR, SECONDS, N_FFT, HOP, N_MFCC = 22050, 10.0, 1024, 256, 13
+# BASELINE.json configs (index) -> parameters; kflop = algorithmic FLOP per frame
+CONFIGS = {
+    2: dict(sr=22050, n_fft=1024, hop=256, n_mfcc=13, n_mels=128, kflop=36.0, baseline_index=1),
+    3: dict(sr=16000, n_fft=512, hop=128, n_mfcc=40, n_mels=128, kflop=24.0, baseline_index=2),
+    5: dict(sr=44100, n_fft=2048, hop=512, n_mfcc=20, n_mels=128, kflop=75.0, baseline_index=4),
+}
+SECONDS = 10.0
 CLIPS_PER_GPU = 1000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
+FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 (vector)
 
 _POOL_CLIPS = None
+_POOL_CFG = None
 
 
-def _pool_init(first: int, per_worker: int) -> None:
+def _pool_init(first: int, per_worker: int, cfg: dict) -> None:
     """Each pool worker pre-generates its own clips so that generation is not timed."""
-    global _POOL_CLIPS
+    global _POOL_CLIPS, _POOL_CFG
     import multiprocessing as mp
     from audio_feature_extraction_amd.synth import make_clip
     from oracle import cpu_ref
+    _POOL_CFG = cfg
     ident = (mp.current_process()._identity or (1,))[0]
-    _POOL_CLIPS = [make_clip(first + (ident * 131 + i) % 1000, SR, SECONDS) for i in range(per_worker)]
-    cpu_ref.extract_stats(_POOL_CLIPS[0], sr=SR, frame_length=N_FFT, hop_length=HOP, n_mfcc=N_MFCC)   # warm
+    _POOL_CLIPS = [make_clip(first + (ident * 131 + i) % 1000, cfg["sr"], SECONDS) for i in range(per_worker)]
+    cpu_ref.extract_stats(_POOL_CLIPS[0], sr=cfg["sr"], frame_length=cfg["n_fft"], hop_length=cfg["hop"], n_mfcc=cfg["n_mfcc"])   # warm
 
 
 def _pool_job(k: int) -> int:
     from oracle import cpu_ref
+    c = _POOL_CFG
     y = _POOL_CLIPS[k % len(_POOL_CLIPS)]
-    out = cpu_ref.extract_stats(y, sr=SR, frame_length=N_FFT, hop_length=HOP, n_mfcc=N_MFCC)
-    return 1 + (out["trim"][1] - out["trim"][0]) // HOP
+    out = cpu_ref.extract_stats(y, sr=c["sr"], frame_length=c["n_fft"], hop_length=c["hop"], n_mfcc=c["n_mfcc"])
+    return 1 + (out["trim"][1] - out["trim"][0]) // c["hop"]
 
 
-def cpu_baseline(samples, offsets, lengths, n_single: int, n_pool: int) -> dict:
-    """Times the CPU oracle on clips of the GPU workload itself: one core (BLAS pinned to one
-    thread) over the first n_single clips, then a spawn-pool over cpu_count-1 workers (the
-    reference's only parallel harness is a multiprocessing.Pool over files)."""
+def usable_cpus() -> int:
+    """Cores this process can actually run on: the affinity mask, cut down to the cgroup's CPU quota when there is one
+    (a GPU box hands a 1-GPU job a share of its host, e.g. 16 of 256 hardware threads; a pool of 255 processes on
+    that share measures the scheduler, not the code)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(q / int(g.read().split()[0]) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(samples, offsets, lengths, cfg: dict, n_single: int, pool_seconds: float) -> dict:
+    """Times the CPU oracle on clips of the GPU workload itself: one core (BLAS pinned to one thread) over the first
+    n_single clips, then a spawn-pool over every core this process may run on but one -- the reference's only parallel
+    harness is a multiprocessing.Pool(cpu_count() - 1) over files
+    (04_feature_extraction_experiment/feature_extraction_for_student.py:168-174)."""
     from oracle import cpu_ref
     try:
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
+    kw = dict(sr=cfg["sr"], frame_length=cfg["n_fft"], hop_length=cfg["hop"], n_mfcc=cfg["n_mfcc"])
     n_single = min(n_single, len(offsets))
     clips = [samples[offsets[i]: offsets[i] + lengths[i]] for i in range(n_single)]
     frames = 0
@@ -77,10 +119,10 @@ def cpu_baseline(samples, offsets, lengths, n_single: int, n_pool: int) -> dict:
         nonlocal frames
         frames = 0
         for y in clips:
-            out = cpu_ref.extract_stats(y, sr=SR, frame_length=N_FFT, hop_length=HOP, n_mfcc=N_MFCC)
-            frames += 1 + (out["trim"][1] - out["trim"][0]) // HOP
+            out = cpu_ref.extract_stats(y, **kw)
+            frames += 1 + (out["trim"][1] - out["trim"][0]) // cfg["hop"]
 
-    cpu_ref.extract_stats(clips[0], sr=SR, frame_length=N_FFT, hop_length=HOP, n_mfcc=N_MFCC)  # warm
+    cpu_ref.extract_stats(clips[0], **kw)  # warm
     t0 = time.perf_counter()
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
@@ -90,24 +132,28 @@ def cpu_baseline(samples, offsets, lengths, n_single: int, n_pool: int) -> dict:
     dt = time.perf_counter() - t0
     res = {
         "value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": f"first {n_single} of the {len(offsets)} clips of this workload (10 s @22050 Hz, 1024/256/13), "
-                  f"numpy/scipy oracle (pre-emphasis, trim, MFCC + deltas, RMS, statistics; no file load, no pYIN), "
-                  f"single thread, {dt:.1f} s",
-        "host_cpus": os.cpu_count(),
+        "sample": f"first {n_single} of the {len(offsets)} clips of this workload (10 s @{cfg['sr']} Hz, "
+                  f"{cfg['n_fft']}/{cfg['hop']}/{cfg['n_mfcc']}), numpy/scipy oracle (pre-emphasis, trim, MFCC + deltas, RMS, "
+                  f"statistics; no file load, no pYIN), single thread, {dt:.1f} s",
+        "host_cpus": os.cpu_count(), "usable_cpus": usable_cpus(),
     }
-    ncpu = os.cpu_count() or 1
-    if n_pool > 0 and ncpu > 2:
+    ncpu = usable_cpus()
+    if pool_seconds > 0 and ncpu > 2:
         import multiprocessing as mp
-        workers = max(1, min(ncpu - 1, 64))
+        workers = max(1, ncpu - 1)
         os.environ.setdefault("OMP_NUM_THREADS", "1")
         os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
-        with mp.get_context("spawn").Pool(workers, initializer=_pool_init, initargs=(0, 4)) as pool:
+        per_clip = dt / max(n_single, 1)
+        n_pool = int(max(workers * 4, min(workers * 64, pool_seconds * workers / max(per_clip, 1e-4))))
+        with mp.get_context("spawn").Pool(workers, initializer=_pool_init, initargs=(0, 4, cfg)) as pool:
             pool.map(_pool_job, range(workers))                 # make sure every worker is up
             t0 = time.perf_counter()
-            fr = sum(pool.map(_pool_job, range(n_pool), chunksize=4))
+            fr = sum(pool.map(_pool_job, range(n_pool), chunksize=2))
             dt2 = time.perf_counter() - t0
         res["all_cores"] = {"value": fr / dt2, "unit": "frames/s", "cores": workers,
-                            "sample": f"{n_pool} clip passes over a {workers}-process spawn pool, {dt2:.1f} s"}
+                            "sample": f"{n_pool} clip passes over a {workers}-process spawn pool "
+                                      f"(every core this job may use but one: {ncpu} by affinity mask and cgroup quota; "
+                                      f"os.cpu_count() = {os.cpu_count()}), {dt2:.1f} s"}
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
@@ -119,14 +165,47 @@ def cpu_baseline(samples, offsets, lengths, n_single: int, n_pool: int) -> dict:
     return res
 
 
+def union_ms(spans) -> float:
+    """Total length of the union of (start, end) intervals."""
+    tot, cur_s, cur_e = 0.0, None, None
+    for s, e in sorted(spans):
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                tot += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        tot += cur_e - cur_s
+    return tot
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (this process has not touched the GPU)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    return max(abs(rc) for rc in rcs)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration (1-based as in BASELINE.md 4): 2 = the headline metric")
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU (default: the BASELINE config)")
     ap.add_argument("--cpu-clips", type=int, default=1000, help="clips timed on one CPU core (0 = skip the CPU baseline)")
-    ap.add_argument("--cpu-pool-clips", type=int, default=8000)
+    ap.add_argument("--cpu-pool-seconds", type=float, default=12.0, help="wall-clock budget of the all-core pool sample (0 = skip)")
     ap.add_argument("--no-timing-events", action="store_true")
     ap.add_argument("--streams", type=int, default=3,
                     help="in-flight sub-batches per GPU: the rank's clips are cut into this many runs, each with its "
@@ -134,24 +213,28 @@ def main() -> None:
                          "kernels and host round trip overlap another's frame kernel")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != max(args.gpus, 1) and world > 1:
+    if world != max(args.gpus, 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     distributed = world > 1
+    cfg = CONFIGS[args.config]
+    SR, N_FFT, HOP, N_MFCC, N_MELS = cfg["sr"], cfg["n_fft"], cfg["hop"], cfg["n_mfcc"], cfg["n_mels"]
 
     import numpy as np
     from audio_feature_extraction_amd.synth import make_batch
 
     n_clips = args.clips
-    workers = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    workers = max(1, min(16, usable_cpus() // max(1, world)))
     samples, offsets, lengths = make_batch(n_clips, SR, SECONDS, first_index=rank * n_clips, workers=workers)
 
     # CPU baseline first (rank 0, N=1 only), before this process touches the GPU
     cpu = None
     if rank == 0 and world == 1 and args.cpu_clips > 0:
-        cpu = cpu_baseline(samples, offsets, lengths, args.cpu_clips, args.cpu_pool_clips)
+        cpu = cpu_baseline(samples, offsets, lengths, cfg, args.cpu_clips, args.cpu_pool_seconds)
 
     import torch
     from audio_feature_extraction_amd import _native as N
@@ -171,6 +254,7 @@ def main() -> None:
             dist.init_process_group(backend=backend)
 
     import threading
+    params = lambda: N.make_params(SR, N_FFT, HOP, N_MFCC, N_MELS)   # noqa: E731
     S = max(1, min(args.streams, n_clips))
     cut = [n_clips * i // S for i in range(S + 1)]
     lanes = []
@@ -179,7 +263,7 @@ def main() -> None:
         base = int(offsets[lo])
         end = int(offsets[hi - 1] + lengths[hi - 1])
         ctx = N.Context(device)
-        plan = N.Plan(ctx, N.make_params(SR, N_FFT, HOP, N_MFCC))
+        plan = N.Plan(ctx, params())
         dbuf = N.DeviceBuffer(ctx, (end - base) * 4)
         dbuf.upload(samples[base:end])
         lanes.append({"ctx": ctx, "plan": plan, "dbuf": dbuf, "offsets": offsets[lo:hi] - base,
@@ -255,26 +339,31 @@ def main() -> None:
     host_dt = time.perf_counter() - h0
     host_frames = int(lanes[0]["out"]["nframes"].sum())
 
-    # frame kernel alone on the GPU (one stream, a few launches, outside the timed region): with several
-    # sub-batches in flight the per-launch HIP-event durations of the timed region include the time a launch
-    # shares the chip with the other streams' launches, so the kernel's own rate is reported beside it
+    # The frame kernel alone on the GPU: the WHOLE batch on one stream, a few launches outside the timed region
+    # (a separate context; the same figure a single-stream rocprofv3 kernel trace of this command gives).
     exclusive = None
-    if not args.no_timing_events:
-        ln = lanes[0]
-        ln["plan"].set_timing(True)
-        ln["plan"].timings(reset=True)
+    if not args.no_timing_events and rank == 0:
+        xc = N.Context(device)
+        xp = N.Plan(xc, params())
+        xb = N.DeviceBuffer(xc, samples.nbytes)
+        xb.upload(samples)
+        xo = None
+        for _ in range(4):
+            xo = xp.extract_batch(xb, offsets, lengths, out=xo)
+        xp.set_timing(True)
+        xp.timings(reset=True)
+        for _ in range(10):
+            xo = xp.extract_batch(xb, offsets, lengths, out=xo)
         torch.cuda.synchronize()
-        if S > 1:
-            ln["done"].clear(); ln["q"].put((5, 0.0)); ln["done"].wait()
-        else:
-            lane_steps(ln, 5)
-        torch.cuda.synchronize()
-        ms, cnt = ln["plan"].timings()["frames"]
+        xt = xp.timings()
+        ms, cnt = xt["frames"]
         if cnt:
-            lane_frames = int(ln["out"]["nframes"].sum())
-            ex_gbs = lane_frames * 4.0 * HOP / (ms / cnt * 1e-3) / 1e9
-            exclusive = {"avg_launch_ms": ms / cnt, "achieved": ex_gbs, "frac": ex_gbs / HBM_PEAK_GBS,
-                         "frames_per_launch": lane_frames}
+            xf = int(xo["nframes"].sum())
+            ex_gbs = xf * 4.0 * HOP / (ms / cnt * 1e-3) / 1e9
+            exclusive = {"avg_launch_ms": ms / cnt, "achieved": ex_gbs, "frac": ex_gbs / HBM_PEAK_GBS, "frames_per_launch": xf,
+                         "launches": cnt, "kernels_ms_per_launch": {k: v[0] / max(v[1], 1) for k, v in xt.items()}}
+        xb.free(); xp.close(); xc.close()
+    if not args.no_timing_events:
         for ln in lanes:
             ln["plan"].set_timing(True)
             ln["plan"].timings(reset=True)
@@ -283,10 +372,11 @@ def main() -> None:
     run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    kt = None
+    kt, spans = None, None
     if not args.no_timing_events:
-        kt = {}
+        kt, spans = {}, []
         for ln in lanes:
+            spans.extend(map(tuple, ln["plan"].intervals("frames")))
             for k, v in ln["plan"].timings().items():
                 a = kt.get(k, (0.0, 0))
                 kt[k] = (a[0] + v[0], a[1] + v[1])
@@ -301,40 +391,48 @@ def main() -> None:
         value = total_frames / elapsed
         roof = None
         if kt is not None and kt["frames"][1] > 0:
-            launches_per_step = kt["frames"][1] / args.steps          # one frame-kernel launch per stream and step
-            avg_ms = kt["frames"][0] / kt["frames"][1]
+            launches = kt["frames"][1]
+            launches_per_step = launches / args.steps          # one frame-kernel launch per stream and step
+            busy = union_ms(spans) if len(spans) == launches else kt["frames"][0]   # GPU time inside the kernel
+            avg_ms = busy / launches
             bytes_per_launch = frames_per_step * 4.0 * HOP / launches_per_step
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            tflops = frames_per_step / launches_per_step * cfg["kflop"] * 1e3 / (avg_ms * 1e-3) / 1e12
             # HBM bytes from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) cannot be collected inside
             # this process; the committed profile of this same command supplies them (a step's launches summed)
             traffic, tsrc = None, None
             try:
                 import glob
-                cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+                cand = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_cfg{args.config}_traffic.json")))
                 if cand and n_clips == CLIPS_PER_GPU:
                     with open(cand[-1]) as fh:
-                        traffic = json.load(fh)["hbm_bytes_per_step"] / launches_per_step
+                        traffic = json.load(fh)["frame_kernel_hbm_bytes_per_step"] / launches_per_step
                     tsrc = os.path.relpath(cand[-1], ROOT)
             except Exception:
                 traffic = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                    "algorithmic_bytes_per_launch": bytes_per_launch, "kernel": "k_frames2 (n_fft=1024, hop=256)",
-                    "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
-                    "streams": S,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "kernel": "k_frames3 (speculative launch)" if (N_FFT, HOP) == (1024, 256) else f"k_frames<{N_FFT}>",
+                    "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step, "streams": S,
+                    "kernel_ms_per_step": busy / args.steps,
+                    "sum_of_launch_ms_per_step": kt["frames"][0] / args.steps,
                     "exclusive": exclusive,
-                    "note": ("achieved/frac come from HIP events around every frame-kernel launch of the timed region; "
-                             "with %d sub-batches in flight a launch shares the GPU with the other streams' launches, "
-                             "'exclusive' is the same kernel timed alone" % S) if S > 1 else None,
+                    "fp32": {"flops_per_frame": cfg["kflop"] * 1e3, "achieved_tflops": tflops, "peak": FP32_PEAK_TFLOPS,
+                             "frac": tflops / FP32_PEAK_TFLOPS,
+                             "note": "algorithmic FLOP per frame (SURVEY.md 8(d)) / the same launch time; vector peak, no MFMA on this path"},
+                    "note": ("avg_launch_ms = union of the launch intervals of all %d streams (HIP events, common device clock) "
+                             "/ launches: GPU time inside the kernel, <= ms_per_step; sum_of_launch_ms counts overlapped time "
+                             "once per stream; 'exclusive' = the whole batch on one stream" % S),
                     "kernels_ms_per_step": {k: v[0] / args.steps for k, v in kt.items()}}
         line = {
-            "metric": "audio frames/sec (sr=22050, n_fft=1024, hop=256, n_mfcc=13)",
+            "metric": f"audio frames/sec (sr={SR}, n_fft={N_FFT}, hop={HOP}, n_mfcc={N_MFCC})",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n_clips}x10s clips @22050 Hz per GPU, frame_length=1024, hop_length=256, "
-                                   f"n_mfcc=13, n_mels=128, hamming, pre-emphasis 0.97 + trim 30 dB + RMS "
-                                   f"(BASELINE configs[{1 if world == 1 else 3}])",
+            "config": {"workload": f"{n_clips}x10s clips @{SR} Hz per GPU, frame_length={N_FFT}, hop_length={HOP}, "
+                                   f"n_mfcc={N_MFCC}, n_mels={N_MELS}, hamming, pre-emphasis 0.97 + trim 30 dB + RMS "
+                                   f"(BASELINE configs[{cfg['baseline_index'] if world == 1 or args.config != 2 else 3}])",
                        "clips_per_gpu": n_clips, "frames_per_gpu_step": frames_per_step,
                        "parallelism": f"file-shard x{world}, no collective; {S} in-flight sub-batches per GPU",
                        "input": "HBM-resident float32"},

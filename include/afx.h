@@ -195,7 +195,8 @@ int afx_preprocess(afx_plan* plan, const float* y, int64_t n,
  * plan's stream.  afx_plan_get_timings returns, per kernel slot, the summed
  * milliseconds and launch count since the last reset. */
 enum {
-  AFX_K_TRIM_BLOCKS = 0,   /* per-512-sample block sums of squares of y_pre */
+  AFX_K_TRIM_BLOCKS = 0,   /* two-pass pipeline: per-512-sample block sums of squares of y_pre; samples-read-once pipeline
+                              (n_fft 1024 / hop 256): the second frame-kernel launch over the frames a trim cut touches */
   AFX_K_TRIM_DECIDE = 1,   /* per-clip max / threshold scan -> [start,end), T */
   AFX_K_FRAMES = 2,        /* fused framing+window+rFFT+power+mel+dB (+RMS)  -- dominant */
   AFX_K_DCT = 3,           /* top_db clamp + DCT-II */
@@ -205,6 +206,11 @@ enum {
 int afx_plan_set_timing(afx_plan* plan, int enable);
 int afx_plan_get_timings(afx_plan* plan, float* ms_sum /*[AFX_K_COUNT]*/,
                          int32_t* launches /*[AFX_K_COUNT]*/, int reset);
+/* The same launches as (start, end) intervals in milliseconds on a clock common to every plan of the device (one
+ * reference event per device), newest `cap` of them, oldest first; *count = intervals held since the last reset.
+ * With several plans (streams) in flight on one GPU their kernels overlap: the time the GPU spends in a kernel is
+ * the union of the plans' intervals, not their sum -- bench.py merges them for `roofline.avg_launch_ms`. */
+int afx_plan_get_intervals(afx_plan* plan, int kernel_slot, double* start_ms, double* end_ms, int cap, int32_t* count);
 
 #ifdef __cplusplus
 }
