@@ -262,7 +262,10 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
       afx_plan_destroy(pl);
       return rc;
     }
-    pl->f3.window = pl->dt.window; pl->f3.w1024 = pl->dt.post;
+    // twiddle sources: post = exp(-2 pi i k / n_fft), k < n_fft / 2;  tw = exp(-2 pi i n / (n_fft / 2)), n < n_fft / 2
+    pl->f3.window = pl->dt.window;
+    pl->f3.w1024 = p->n_fft == 2048 ? pl->dt.tw : pl->dt.post;
+    pl->f3.w2048 = pl->dt.post;
     pl->f3.mel_rounds = t.f3mel.rounds; pl->f3.mel_wfloats = (int32_t)t.f3mel.w.size();
     for (int r = 0; r < kF3MaxRounds; ++r)
       pl->f3.mel_rp[r] = (uint32_t)t.f3mel.nb[r] | ((uint32_t)t.f3mel.width[r] << 4) | ((uint32_t)t.f3mel.woff[r] << 8);
@@ -484,11 +487,11 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
     // the samples are read once: frames before the trim decision (which the same pass feeds), then the few frames a cut touches
     const int max_items = n * kF3ItemsPerClip;
     HIP_TRY(hipMemsetAsync(pl->n_items.p, 0, 16, s));
-    TIMED(AFX_K_FRAMES, launch_frames3(s, d_samples, d_info, (const BlockDesc*)pl->blocks_spec.p, pl->nblocks, nullptr, pl->f3, kp,
+    TIMED(AFX_K_FRAMES, launch_frames3_any(s, d_samples, d_info, (const BlockDesc*)pl->blocks_spec.p, pl->nblocks, nullptr, pl->f3, kp,
                                        (float*)pl->logmel.p, (float*)pl->blockmax.p, (float*)pl->bsum.p, true, pl->n_cu));
     TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide3(s, d_clips, d_info, (const float*)pl->bsum.p, (const float*)pl->blockmax.p,
                                                  (BlockDesc*)pl->items.p, (int*)pl->n_items.p, max_items, (float*)pl->rms.p, n, kp));
-    TIMED(AFX_K_TRIM_BLOCKS, launch_frames3(s, d_samples, d_info, (const BlockDesc*)pl->items.p, max_items, (const int*)pl->n_items.p,
+    TIMED(AFX_K_TRIM_BLOCKS, launch_frames3_any(s, d_samples, d_info, (const BlockDesc*)pl->items.p, max_items, (const int*)pl->n_items.p,
                                             pl->f3, kp, (float*)pl->logmel.p, nullptr, nullptr, false, pl->n_cu));
     TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax, true, true));
   } else {
@@ -503,7 +506,7 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
       HIP_TRY(hipMemsetAsync(d_stamps, 0, (size_t)grid * kWaves * kStampPhases * 8, s));
     }
     if (f3)
-      TIMED(AFX_K_FRAMES, launch_frames3(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks, nullptr, pl->f3, kp,
+      TIMED(AFX_K_FRAMES, launch_frames3_any(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks, nullptr, pl->f3, kp,
                                          (float*)pl->logmel.p, nullptr, nullptr, false, pl->n_cu));
     else
       TIMED(AFX_K_FRAMES, launch_frames(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks,

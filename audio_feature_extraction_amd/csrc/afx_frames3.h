@@ -30,7 +30,9 @@ struct HostF3Mel {
 
 struct F3Tables {
   const float* window;      // n_fft floats
-  const float* w1024;       // exp(-2 pi i k / 1024), k < 512, as float2
+  const float* w1024;       // twiddle source of the complex FFT: exp(-2 pi i k / 1024), k < 512 (n_fft 1024, 2048);
+                            // exp(-2 pi i k / 512), k < 256 (n_fft 512), as float2
+  const float* w2048;       // n_fft 2048 only: exp(-2 pi i k / 2048), k < 1024 (real-FFT split)
   const float* mel_w;
   const int32_t* mel_meta;
   int32_t mel_rounds;
@@ -38,8 +40,10 @@ struct F3Tables {
   uint32_t mel_rp[kF3MaxRounds];   // per round: batches | width << 4 | weight offset (floats) << 8
 };
 
-// mel_dense: n_mels x n_bins (librosa float32 values); max_slot: highest float2 slot of the image a padded tap may read
-void build_f3_mel(const std::vector<float>& mel_dense, int n_mels, int n_bins, int max_slot, HostF3Mel& out);
+// mel_dense: n_mels x n_bins (librosa float32 values); max_slot: highest bin slot of the image a padded tap may read;
+// lanes: lanes that share one spectrum (64, or 32 when a wave holds two); align: bins per 16-byte read (2: (A, B) pairs
+// of a frame pair, 4: one frame)
+void build_f3_mel(const std::vector<float>& mel_dense, int n_mels, int n_bins, int max_slot, int lanes, int align, HostF3Mel& out);
 
 size_t frames3_lds_bytes(int waves, const F3Tables& ft);
 bool frames3_eligible(const KParams& kp, const F3Tables& ft);
@@ -49,6 +53,20 @@ int frames3_waves(const F3Tables& ft);
 hipError_t launch_frames3(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                           const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
                           float* blockmax, float* bsum, bool spec, int n_cu);
+// the same for n_fft 2048 / hop 512 (afx_frames3s.hip: one frame per FFT, real-FFT split) and n_fft 512 / hop 128
+// (afx_frames3d.hip: two frame pairs per wave)
+size_t frames3s_lds_bytes(int waves, const F3Tables& ft);
+size_t frames3d_lds_bytes(int waves, const F3Tables& ft);
+hipError_t launch_frames3s(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
+                           const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
+                           float* blockmax, float* bsum, bool spec, int n_cu);
+hipError_t launch_frames3d(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
+                           const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
+                           float* blockmax, float* bsum, bool spec, int n_cu);
+// dispatch on kp.n_fft
+hipError_t launch_frames3_any(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
+                              const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
+                              float* blockmax, float* bsum, bool spec, int n_cu);
 constexpr int kF3ItemsPerClip = 6;         // redo-list capacity per clip (k_trim_decide3)
 hipError_t launch_trim_decide3(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum, const float* blockmax,
                                BlockDesc* items, int* n_items, int max_items, float* rms_rows, int n_clips, const KParams& kp);

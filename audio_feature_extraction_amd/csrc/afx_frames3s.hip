@@ -1,0 +1,345 @@
+// k_frames3s: the wave-level frame kernel for n_fft = 2048 / hop = 512 (BASELINE.json configs[4], the "music"
+// configuration of 04_feature_extraction_experiment/feature_extractor.py:19-23; librosa stft / mel / power_to_db
+// semantics as in oracle/cpu_ref.py).  Same design as k_frames3 (afx_frames3.hip) -- autonomous waves, one 8.5 KB LDS
+// image per wave, packed-f32 butterflies, samples read once before the trim decision -- with ONE frame per FFT:
+//   * the 2048 real samples of a frame are packed as 1024 complex points c[n] = x[2n] + i x[2n+1]; a lane holds points
+//     l + 64 u as the float2 rows it loads (8 bytes per lane, 512 contiguous bytes per wave-load), so window and
+//     pre-emphasis are packed instructions on whole rows; hop = 512 samples = 4 rows: a frame keeps 12 rows of its
+//     predecessor and takes in 4;
+//   * the same 16 x 8 x 8 complex FFT as k_frames3; its last pass hands every lane Z[k] and Z[1024 - k], exactly the
+//     operands of the real-FFT split X[k] = (E - i W^k O) / 2, X[1024 - k] = conj((E + i W^k O) / 2) with
+//     E = Z[k] + conj Z[1024 - k], O = Z[k] - conj Z[1024 - k], W = exp(-2 pi i / 2048) -- one twiddle product per
+//     bin pair, both powers formed as one packed pair;
+//   * the power spectrum of the frame (1025 floats) takes the image's place; a mel lane reads four bins per 16-byte
+//     read (schedule: afx_tables.cpp build_f3_mel with align = 4).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "afx_device.h"
+#include "afx_frames3.h"
+#include "afx_frames3_dev.h"
+
+namespace afx {
+
+constexpr int kF3sTabFloats = 2048 + 1024 + 2048;      // FFT twiddles (as k_frames3) + split twiddles 8 x 64 float2 + window 16 x 64 float2
+
+size_t frames3s_lds_bytes(int waves, const F3Tables& ft) {
+  return (size_t)(waves * kF3ExFloats + kF3sTabFloats + ft.mel_wfloats + ft.mel_rounds * 64) * sizeof(float);
+}
+
+template <int FMT, int WAVES, bool SPEC>
+__global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict__ samples,
+                                                         ClipInfo* __restrict__ info,
+                                                         const BlockDesc* __restrict__ blocks, int nblocks,
+                                                         const int* __restrict__ nblocks_dev,
+                                                         F3Tables ft, KParams kp,
+                                                         float* __restrict__ logmel,
+                                                         float* __restrict__ blockmax,
+                                                         float* __restrict__ bsum) {
+  constexpr int N = 2048, HOP = 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const tabs = smem + WAVES * kF3ExFloats;
+  v2* const T2 = reinterpret_cast<v2*>(tabs);                 // [r][16]: W_128^(c r)
+  v2* const T3a = reinterpret_cast<v2*>(tabs + 256);          // [r-1][lane]: W_1024^(ja r)
+  v2* const T3b = reinterpret_cast<v2*>(tabs + 256 + 896);    // [r-1][lane]: W_1024^(jb r)
+  v2* const TS = reinterpret_cast<v2*>(tabs + 2048);          // [s][lane]: W_2048^k of the lane's bin pair s
+  v2* const WT = reinterpret_cast<v2*>(tabs + 2048 + 1024);   // [u][lane]: window pair of row u, x 0.5
+  float* const MW = tabs + kF3sTabFloats;                     // mel weights [round][batch][lane][4]
+  int* const MM = reinterpret_cast<int*>(MW + ft.mel_wfloats);   // mel meta [round][lane]
+  v2* const E = reinterpret_cast<v2*>(smem + wave * kF3ExFloats);
+  float* const XB = reinterpret_cast<float*>(E);
+
+  {
+    const v2* w1024 = reinterpret_cast<const v2*>(ft.w1024);       // exp(-2 pi i k / 1024), k < 512
+    const v2* w2048 = reinterpret_cast<const v2*>(ft.w2048);       // exp(-2 pi i k / 2048), k < 1024
+    auto W = [&](int m) { const v2 v = w1024[m & 511]; return (m & 512) ? -v : v; };
+    if (tid < 128) T2[tid] = W(8 * (tid >> 4) * (tid & 15));
+    if (tid < 64) {
+      const int jbt = tid ? 128 - tid : 64;
+#pragma unroll
+      for (int r = 1; r < 8; ++r) { T3a[(r - 1) * 64 + tid] = W(tid * r); T3b[(r - 1) * 64 + tid] = W(jbt * r); }
+      // bin pair s of a lane: k = lane + 128 s; lane 0 holds the self-mirrored butterflies 0 and 64, its pairs 4..7 are k = 64 + 128 s
+#pragma unroll
+      for (int s = 0; s < 8; ++s) TS[s * 64 + tid] = w2048[((tid == 0 && s >= 4) ? 64 : tid) + 128 * s];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int n = 2 * (tid + 64 * u);
+        WT[u * 64 + tid] = v2{0.5f * ft.window[n], 0.5f * ft.window[n + 1]};
+      }
+    }
+    for (int i = tid; i < ft.mel_wfloats; i += WAVES * 64) MW[i] = ft.mel_w[i];
+    for (int i = tid; i < ft.mel_rounds * 64; i += WAVES * 64) MM[i] = ft.mel_meta[i];
+    for (int i = lane; i < kF3ExFloats; i += 64) XB[i] = 0.f;
+  }
+  __syncthreads();
+
+  const v2 H = {0.70710678118654752440f, 0.70710678118654752440f};
+  const v2 W1 = {0.92387953251128675613f, -0.38268343236508977173f};      // W16^1
+  const v2 W3 = {0.38268343236508977173f, -0.92387953251128675613f};      // W16^3
+  const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
+  const float b1 = kp.preemph_b1;
+  const int M = kp.n_mels;
+  const int jb = lane ? 128 - lane : 64;
+  const int lq = lane ? lane : 64;         // first bin of the lane's pairs 4..7 (minus 128 s)
+  v2* const e1w = E + 17 * lane;
+  const v2* const e1r = E + 17 * (lane >> 4) + (lane & 15);
+  v2* const e2w = E + 128 * (lane >> 4) + (lane & 15);
+  const v2* const ea = E + lane;
+  const v2* const eb = E + jb;
+
+  auto raw_ld = [&](int64_t idx) -> float {
+    if constexpr (FMT == AFX_FMT_S16) return (float)((const int16_t*)samples)[idx] * (1.0f / 32768.0f);
+    else return ((const float*)samples)[idx];
+  };
+  typedef typename std::conditional<FMT == AFX_FMT_S16, int16_t, float>::type sample_t;
+  auto row_ld = [&](const sample_t* base, unsigned idx) -> float {
+    if constexpr (FMT == AFX_FMT_S16) return (float)base[idx] * (1.0f / 32768.0f);
+    else return base[idx];
+  };
+  const int n_rounds = ft.mel_rounds;
+  const float amin = kp.amin;
+  if (nblocks_dev) nblocks = *nblocks_dev;
+
+  // sum of squares of four float2 rows (one 512-sample sub-block of the pre-emphasised signal), wave-wide
+  auto subblock = [&](v2 r0, v2 r1, v2 r2, v2 r3, const BlockDesc& bd, int j) {
+    v2 a = r0 * r0; a = r1 * r1 + a; a = r2 * r2 + a; a = r3 * r3 + a;
+    float q = a.x + a.y;
+    q += F3_DPP(q, 0xB1); q += F3_DPP(q, 0x4E); q += F3_DPP(q, 0x141); q += F3_DPP(q, 0x140);
+    const int qi = __float_as_int(q);
+    const float t = (__int_as_float(__builtin_amdgcn_readlane(qi, 0)) + __int_as_float(__builtin_amdgcn_readlane(qi, 16))) +
+                    (__int_as_float(__builtin_amdgcn_readlane(qi, 32)) + __int_as_float(__builtin_amdgcn_readlane(qi, 48)));
+    if (j >= 0 && j < bd.pad_[1]) {
+      if (lane == 0) bsum[bd.pad_[0] + j] = t;
+      if (!(fabsf(t) < INFINITY)) {
+        const bool bad = !(isfinite(r0.x) && isfinite(r0.y) && isfinite(r1.x) && isfinite(r1.y) &&
+                           isfinite(r2.x) && isfinite(r2.y) && isfinite(r3.x) && isfinite(r3.y));
+        if (__any(bad) && lane == 0) atomicOr(&info[bd.clip].nonfinite, 1u);
+      }
+    }
+  };
+
+  const int total_waves = gridDim.x * WAVES;
+  for (int b = blockIdx.x * WAVES + wave; b < nblocks; b += total_waves) {
+    const BlockDesc bd = blocks[b];
+    if (!bd.active) continue;
+    const int Tleft = bd.T - bd.t0;
+    const int nfr = Tleft >= 16 ? 16 : Tleft;
+    const int64_t sbase = bd.sample_base;
+    const sample_t* const sp = (const sample_t*)samples + sbase;
+    auto interior = [&](int j0, int j1) -> bool {
+      return (j0 - 1 >= bd.have_lo) && (j1 <= bd.have_hi) && (j0 >= bd.keep_lo) && (j1 <= bd.keep_hi);
+    };
+    auto edge_sample = [&](int j) -> float {
+      const int lo = bd.have_lo, hi = bd.have_hi - 1;
+      const int jc = j < lo ? lo : (j > hi ? hi : j), jp = (j - 1) < lo ? lo : ((j - 1) > hi ? hi : (j - 1));
+      const float y = (jc == j) ? raw_ld(sbase + jc) : 0.f;
+      const float yp = (jp == j - 1) ? raw_ld(sbase + jp) : 0.f;
+      float v = y;
+      if (pre) {
+        v = f3_pre1(y, yp, b1);
+        if (j == lo) v = f3_pre0(raw_ld(bd.clip_off), raw_ld(bd.clip_off + 1));
+      }
+      return (j >= bd.keep_lo && j < bd.keep_hi) ? v : 0.f;
+    };
+    // one float2 row: samples j0 + 2 lane, + 1 (pre-emphasised)
+    auto pre_row = [&](float x0, float x1, float xp) -> v2 {
+      return pre ? v2{f3_pre1(x0, xp, b1), f3_pre1(x1, x0, b1)} : v2{x0, x1};
+    };
+
+    // ---- rows of the first frame: staged samples [0, 2048)
+    v2 R[16];
+    if (interior(0, N)) {
+      float x0[16], x1[16], xp[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        x0[u] = row_ld(sp, 128 * u + 2 * lane); x1[u] = row_ld(sp, 128 * u + 2 * lane + 1); xp[u] = row_ld(sp - 1, 128 * u + 2 * lane);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) R[u] = pre_row(x0[u], x1[u], xp[u]);
+    } else {
+#pragma unroll 1
+      for (int u = 0; u < 16; ++u) {
+        XB[128 * u + 2 * lane] = edge_sample(128 * u + 2 * lane);
+        XB[128 * u + 2 * lane + 1] = edge_sample(128 * u + 2 * lane + 1);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) R[u] = E[64 * u + lane];
+    }
+    if constexpr (SPEC) {
+      // rows 8..11 / 12..15 are sub-blocks t0 / t0 + 1 of the clip; the former belongs to the previous block unless this is the clip's first
+      if (bd.t0 == 0) subblock(R[8], R[9], R[10], R[11], bd, 0);
+      subblock(R[12], R[13], R[14], R[15], bd, bd.t0 + 1);
+    }
+    float lmax = -INFINITY;
+    float* const tile = logmel + bd.frame_slot * (int64_t)M;     // [frame][mel]
+
+#pragma unroll 1
+    for (int f = 0; f < nfr; ++f) {
+      // ---- c[n] = w (x[2n] + i x[2n+1])
+      v2 z[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) z[u] = R[u] * ldv(WT + u * 64 + lane);
+#pragma unroll
+      for (int u = 0; u < 12; ++u) R[u] = R[u + 4];
+      const bool more = f + 1 < nfr;
+      const int jn = HOP * f + N;                          // the next frame's 4 new rows: staged samples [jn, jn + 512)
+      const bool nint = more && interior(jn, jn + HOP);
+
+      // ---- 1024-point complex FFT (k_frames3's schedule)
+      f3_dft16(z, H, W1, W3);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) e1w[k] = z[k];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 68 * u);
+      {
+        v2 tw[8];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) tw[r] = ldv(T2 + r * 16 + (lane & 15));
+        v2 xa[8], xb[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { xa[r] = z[2 * r]; xb[r] = z[2 * r + 1]; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) cmul2(xa[r], tw[r], xb[r], tw[r]);
+        f3_dft8(xa, H); f3_dft8(xb, H);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { e2w[16 * r] = xa[r]; e2w[16 * r + 512] = xb[r]; }
+      }
+      v2 A[8], B[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { A[r] = ldv(ea + 128 * r); B[r] = ldv(eb + 128 * r); }
+#pragma unroll
+      for (int r = 1; r < 8; ++r) cmul2(A[r], ldv(T3a + (r - 1) * 64 + lane), B[r], ldv(T3b + (r - 1) * 64 + lane));
+      f3_dft8(A, H); f3_dft8(B, H);
+      // A[s] = Z[lane + 128 s], B[s] = Z[jb + 128 s]; mirror of A[s] is B[7-s]; lane 0 re-seated as in k_frames3
+      const v2 nyq = A[4];
+      if (lane == 0) { A[4] = B[4]; B[4] = A[5]; A[5] = B[5]; B[5] = A[6]; A[6] = B[6]; B[6] = A[7]; A[7] = B[7]; B[7] = A[0]; }
+      // ---- real-FFT split + power: pair s = (Z[k], Z[1024 - k]), k = lane + 128 s (lane 0, s >= 4: 64 + 128 s)
+      //   E = Z[k] + conj Z[N-k], O = Z[k] - conj Z[N-k], T = W^k O;  |X[k]|^2 = |E - iT|^2, |X[N-k]|^2 = |E + iT|^2
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const v2 za = A[s], zb = B[7 - s];
+        v2 Ev, Ov;
+        asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(Ev) : "v"(za), "v"(zb));      // (za.x + zb.x, za.y - zb.y)
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(Ov) : "v"(za), "v"(zb));      // (za.x - zb.x, za.y + zb.y)
+        const v2 T = cmul(Ov, ldv(TS + s * 64 + lane));
+        v2 U, V;      // U = (Xp.x, Xm.x) = (E.x + T.y, E.x - T.y);  V = (Xp.y, Xm.y) = (E.y - T.x, E.y + T.x)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(U) : "v"(Ev), "v"(T));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(V) : "v"(Ev), "v"(T));
+        const v2 P = U * U + V * V;                                  // (|X[k]|^2, |X[N-k]|^2)
+        const int k0 = (s < 4 ? lane : lq) + 128 * s;
+        XB[k0] = P.x; XB[1024 - k0] = P.y;
+      }
+      if (lane == 0) XB[512] = 4.f * (nyq.x * nyq.x + nyq.y * nyq.y);
+
+      // ---- the next frame's new rows are fetched under the mel phase
+      float nx0[4], nx1[4], nxp[4];
+      if (nint) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          nx0[i] = row_ld(sp + jn, 128 * i + 2 * lane); nx1[i] = row_ld(sp + jn, 128 * i + 2 * lane + 1); nxp[i] = row_ld(sp + jn - 1, 128 * i + 2 * lane);
+        }
+      }
+      // ---- mel + dB: a lane walks 4 * nb consecutive bins of its filter, four per 16-byte read
+      const bool vF = f < Tleft;
+      float* const rowF = tile + (unsigned)(f * M);
+#pragma unroll 1
+      for (int rd = 0; rd < n_rounds; ++rd) {
+        const uint32_t rp = ft.mel_rp[rd];
+        const int meta = MM[rd * 64 + lane];
+        const float4* pp = reinterpret_cast<const float4*>(XB + (meta & 2047));
+        const float4* ww = reinterpret_cast<const float4*>(MW + (rp >> 8)) + lane;
+        const int nb = rp & 15, wd = (rp >> 4) & 15;
+        v2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#define F3_BATCH(i)                                                                  \
+        if (nb > (i)) {                                                              \
+          const float4 c = ww[64 * (i)];                                             \
+          const float4 q = pp[(i)];                                                  \
+          a0 = v2{q.x, q.y} * v2{c.x, c.y} + a0; a1 = v2{q.z, q.w} * v2{c.z, c.w} + a1; \
+        }
+        F3_BATCH(0) F3_BATCH(1) F3_BATCH(2) F3_BATCH(3) F3_BATCH(4) F3_BATCH(5) F3_BATCH(6) F3_BATCH(7)
+#undef F3_BATCH
+        const v2 a = a0 + a1;
+        float acc = a.x + a.y;
+        if (wd >= 2) acc += F3_DPP(acc, 0xB1);
+        if (wd >= 4) acc += F3_DPP(acc, 0x4E);
+        if (wd >= 8) acc += F3_DPP(acc, 0x141);
+        const float L = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(acc, amin));
+        if (meta & (1 << 20)) {
+          const unsigned m = (meta >> 11) & 511;
+          if (vF) { rowF[m] = L; lmax = f3_max(lmax, L); }
+        }
+      }
+
+      // ---- take in the next frame's 4 new rows (sub-block t0 + f + 2 of the clip)
+      if (more) {
+        if (nint) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) R[12 + i] = pre_row(nx0[i], nx1[i], nxp[i]);
+        } else {
+#pragma unroll 1
+          for (int i = 0; i < 4; ++i) {
+            XB[128 * i + 2 * lane] = edge_sample(jn + 128 * i + 2 * lane);
+            XB[128 * i + 2 * lane + 1] = edge_sample(jn + 128 * i + 2 * lane + 1);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) R[12 + i] = E[64 * i + lane];
+        }
+        if constexpr (SPEC) subblock(R[12], R[13], R[14], R[15], bd, bd.t0 + f + 2);
+      }
+    }
+    {
+      float v = lmax;
+      v = f3_max(v, F3_DPP(v, 0xB1)); v = f3_max(v, F3_DPP(v, 0x4E)); v = f3_max(v, F3_DPP(v, 0x141)); v = f3_max(v, F3_DPP(v, 0x140));
+      const int vi = __float_as_int(v);
+      const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+      const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+      const float mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+      if constexpr (SPEC) { if (lane == 0) blockmax[b] = mx; }
+      else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx)); }
+    }
+  }
+}
+
+int frames3s_waves(const F3Tables& ft) {
+  static const int forced = getenv("AFX_F3_WAVES") ? atoi(getenv("AFX_F3_WAVES")) : 0;
+  if (forced == 12 || forced == 16) return frames3s_lds_bytes(forced, ft) <= 160 * 1024 ? forced : 12;
+  return frames3s_lds_bytes(16, ft) <= 160 * 1024 ? 16 : 12;
+}
+
+template <int FMT, int WAVES, bool SPEC>
+static hipError_t launch_frames3s_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
+                                    int nblocks, const int* nblocks_dev, const F3Tables& ft, const KParams& kp,
+                                    float* logmel, float* blockmax, float* bsum, int n_cu) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3s<FMT, WAVES, SPEC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  const int grid = std::max(1, std::min(n_cu, (nblocks + WAVES - 1) / WAVES));
+  hipLaunchKernelGGL((k_frames3s<FMT, WAVES, SPEC>), dim3(grid), dim3(WAVES * 64), frames3s_lds_bytes(WAVES, ft), s,
+                     samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum);
+  return hipGetLastError();
+}
+
+hipError_t launch_frames3s(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
+                           const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
+                           float* blockmax, float* bsum, bool spec, int n_cu) {
+  const int waves = frames3s_waves(ft);
+#define AFX_F3S_GO(FMT, W)                                                                                                    \
+  (spec ? launch_frames3s_t<FMT, W, true>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu) \
+        : launch_frames3s_t<FMT, W, false>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu))
+  if (kp.fmt == AFX_FMT_S16) return waves == 16 ? AFX_F3S_GO(AFX_FMT_S16, 16) : AFX_F3S_GO(AFX_FMT_S16, 12);
+  return waves == 16 ? AFX_F3S_GO(AFX_FMT_F32, 16) : AFX_F3S_GO(AFX_FMT_F32, 12);
+#undef AFX_F3S_GO
+}
+
+}  // namespace afx

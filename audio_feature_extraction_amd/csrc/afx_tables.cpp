@@ -197,7 +197,7 @@ static void build_mel_taps(const afx_params& p, const std::vector<float>& W, Mel
 // k_frames3's mel schedule (afx_frames3.h).  Filters sorted by tap count are cut into rounds of 64 / width filters;
 // a dynamic programme picks the widths: a round costs its batches (4 reads + 1 weight read + 4 packed FMAs each)
 // plus a fixed finish (reduction, two logs, two stores).
-void build_f3_mel(const std::vector<float>& W, int M, int NB, int max_slot, HostF3Mel& out) {
+void build_f3_mel(const std::vector<float>& W, int M, int NB, int max_slot, int lanes, int align, HostF3Mel& out) {
   out = HostF3Mel();
   std::vector<int> first(M, 0), nnz(M, 0), order(M);
   for (int m = 0; m < M; ++m) {
@@ -211,8 +211,9 @@ void build_f3_mel(const std::vector<float>& W, int M, int NB, int max_slot, Host
   // dp[r][i]: cheapest way to place the first i filters (sorted) in r rounds
   std::vector<std::vector<int>> dp(kF3KernelRounds + 1, std::vector<int>(M + 1, INF)), from_w = dp, from_i = dp;
   dp[0][0] = 0;
-  // a lane's first bin is even (16-byte reads of two (A, B) bins): a filter starting on an odd bin takes one tap more
-  for (int m = 0; m < M; ++m) if (nnz[m] > 0 && (first[m] & 1)) { first[m] -= 1; nnz[m] += 1; }
+  // a lane's first bin is a multiple of `align` (16-byte reads: two (A, B) bins of a frame pair, or four bins of one
+  // frame): a filter starting in between takes the taps before it as zeros
+  for (int m = 0; m < M; ++m) if (nnz[m] > 0 && (first[m] % align)) { const int d = first[m] % align; first[m] -= d; nnz[m] += d; }
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nnz[a] < nnz[b]; });
   auto batches = [&](int i, int j, int w) {            // filters [i, j) at width w
     const int maxt = nnz[order[j - 1]];
@@ -223,7 +224,8 @@ void build_f3_mel(const std::vector<float>& W, int M, int NB, int max_slot, Host
     for (int i = 0; i < M; ++i) {
       if (dp[r][i] >= INF) continue;
       for (int w = 1; w <= 8; w *= 2) {
-        const int j = std::min(M, i + 64 / w);
+        if (w > lanes) continue;
+        const int j = std::min(M, i + lanes / w);
         const int nb = batches(i, j, w);
         if (nb > kF3MaxBatches) continue;
         const int lg = w == 1 ? 0 : (w == 2 ? 1 : (w == 4 ? 2 : 3));
@@ -256,17 +258,17 @@ void build_f3_mel(const std::vector<float>& W, int M, int NB, int max_slot, Host
                                         {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
                                         {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
                                         {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
-      const int n = i1 - i0;
+      const int n = i1 - i0, ngrp = lanes / 16;
       std::vector<int> cell_item(64, -1), item_cell(n, -1);
-      auto max_shift = [&](int it) {                       // slots (2 bins) the first bin may move down
+      auto max_shift = [&](int it) {                       // slots (`align` bins) the first bin may move down
         const int m = order[i0 + it];
-        return std::max(0, std::min(first[m] / 2, (S - nnz[m]) / 2));
+        return std::max(0, std::min(first[m] / align, (S - nnz[m]) / align));
       };
       std::vector<char> seen;
       std::function<bool(int)> place = [&](int it) -> bool {
-        const int m = order[i0 + it], s0 = first[m] / 2;
+        const int m = order[i0 + it], s0 = first[m] / align;
         for (int d = 0; d <= max_shift(it); ++d)
-          for (int g = 0; g < 4; ++g) {
+          for (int g = 0; g < ngrp; ++g) {
             const int c = g * 16 + ((s0 - d) & 15);
             if (seen[c]) continue;
             seen[c] = 1;
@@ -288,7 +290,7 @@ void build_f3_mel(const std::vector<float>& W, int M, int NB, int max_slot, Host
         lane_of[it] = glanes[g][fill[g]++];
         lane_used[lane_of[it]] = 1;
         int d = 0;
-        while ((((first[m] / 2) - d) & 15) != (c & 15)) ++d;
+        while ((((first[m] / align) - d) & 15) != (c & 15)) ++d;
         shift_of[it] = d;
       }
       for (int it = 0; it < n; ++it)
@@ -302,7 +304,7 @@ void build_f3_mel(const std::vector<float>& W, int M, int NB, int max_slot, Host
       const int m = order[i];
       for (int q = 0; q < w; ++q) {
         const int lane = lane_of[i - i0] + q;
-        int bin0 = first[m] - 2 * shift_of[i - i0] + q * S;
+        int bin0 = first[m] - align * shift_of[i - i0] + q * S;
         const bool live = nnz[m] > 0 && bin0 < first[m] + nnz[m];
         if (!live) bin0 = 0;
         if (bin0 + S - 1 > max_slot) return;          // a padded tap would leave the image: unusable
@@ -315,6 +317,14 @@ void build_f3_mel(const std::vector<float>& W, int M, int NB, int max_slot, Host
       }
     }
   }
+  if (lanes == 32)            // two frame pairs per wave: the upper half-wave walks the same schedule on its own image
+    for (int r = 0; r < best_r; ++r)
+      for (int l = 0; l < 32; ++l) {
+        out.meta[(size_t)r * 64 + 32 + l] = out.meta[(size_t)r * 64 + l];
+        for (int bt = 0; bt < out.nb[r]; ++bt)
+          for (int c = 0; c < 4; ++c)
+            out.w[out.woff[r] + ((size_t)bt * 64 + 32 + l) * 4 + c] = out.w[out.woff[r] + ((size_t)bt * 64 + l) * 4 + c];
+      }
   out.usable = true;
 }
 
@@ -357,7 +367,11 @@ void build_host_tables(const afx_params& p, HostTables& t) {
   build_mel_dense(p, t.mel_dense, mel_f);
   build_mel_blocks(p, t.mel_dense, mel_f, t.mel);
   build_mel_taps(p, t.mel_dense, t.taps);
-  build_f3_mel(t.mel_dense, M, N / 2 + 1, kF3ExFloats / 2 - 1, t.f3mel);
+  // wave-level frame kernels: 1024 -> one frame pair per wave (bins as (A, B) pairs), 2048 -> one frame per wave (bins
+  // as floats), 512 -> two frame pairs per wave, one per half-wave with half the image each
+  if (N == 1024) build_f3_mel(t.mel_dense, M, N / 2 + 1, kF3ExFloats / 2 - 1, 64, 2, t.f3mel);
+  else if (N == 2048) build_f3_mel(t.mel_dense, M, N / 2 + 1, kF3ExFloats - 1, 64, 4, t.f3mel);
+  else if (N == 512) build_f3_mel(t.mel_dense, M, N / 2 + 1, kF3ExFloats / 4 - 1, 32, 2, t.f3mel);
   t.dct.resize((size_t)K * M);
   for (int k = 0; k < K; ++k) {
     const double s = k == 0 ? std::sqrt(1.0 / M) : std::sqrt(2.0 / M);

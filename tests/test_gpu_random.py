@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 SR = 22050
 
 
-def _random_clip(rng, i):
+def _random_clip(rng, i, sr=SR, scale=1):
     kind = rng.integers(0, 6)
-    n = int(rng.integers(2, 9000)) if kind == 0 else int(rng.integers(2304, 45000))
-    y = make_clip(300 + i, SR, max(n / SR, 0.01))[:n].copy()
+    n = int(rng.integers(2, 9000 * scale)) if kind == 0 else int(rng.integers(2304 * scale, 45000 * scale))
+    y = make_clip(300 + i, sr, max(n / sr, 0.01))[:n].copy()
     if y.size < n:
         y = np.resize(y, n)
     if kind == 1:                                   # leading / trailing digital silence
@@ -34,13 +34,19 @@ def _random_clip(rng, i):
     return y.astype(np.float32)
 
 
-@pytest.mark.parametrize("seed,fmt", [(1, "f32"), (2, "f32"), (3, "s16")])
-def test_random_ragged_batches(seed, fmt):
+# the three wave-level frame kernels (n_fft 1024: one frame pair per wave; 2048: one frame, real-FFT split; 512: two
+# pairs per wave), each with float32 and int16 packing
+@pytest.mark.parametrize("seed,fmt,cfg", [(1, "f32", (22050, 1024, 256, 13)), (2, "f32", (22050, 1024, 256, 13)),
+                                          (3, "s16", (22050, 1024, 256, 13)),
+                                          (4, "f32", (44100, 2048, 512, 20)), (5, "s16", (44100, 2048, 512, 20)),
+                                          (6, "f32", (16000, 512, 128, 40)), (7, "s16", (16000, 512, 128, 40))])
+def test_random_ragged_batches(seed, fmt, cfg):
     rng = np.random.default_rng(seed)
     ctx = N.Context(0)
-    plan = N.Plan(ctx, N.make_params(SR, 1024, 256, 13))
+    SR, n_fft, hop, K = cfg
+    plan = N.Plan(ctx, N.make_params(SR, n_fft, hop, K))
     try:
-        clips = [_random_clip(rng, 100 * seed + i) for i in range(28)]
+        clips = [_random_clip(rng, 100 * seed + i, SR, max(1, n_fft // 1024)) for i in range(28)]
         if fmt == "s16":
             q = [np.clip(np.rint(c.astype(np.float64) * 32768), -32768, 32767).astype(np.int16) for c in clips]
             clips = [(c.astype(np.float32) / np.float32(32768.0)) for c in q]
@@ -54,14 +60,14 @@ def test_random_ragged_batches(seed, fmt):
         n_ok = 0
         for i, c in enumerate(clips):
             try:
-                ref = oracle_stats(c, SR, 1024, 256, 13)
+                ref = oracle_stats(c, SR, n_fft, hop, K)
             except ValueError:
                 assert out["status"][i] == N.CLIP_TOO_SHORT, (i, c.size, out["status"][i])
                 continue
             assert out["status"][i] == N.CLIP_OK, (i, c.size, out["status"][i])
             assert tuple(out["trim"][i]) == tuple(ref["trim"]), (i, out["trim"][i], ref["trim"])
             check_frames(out["frames"][i], ref, f"rand{seed}-{i}")
-            check_stats(out["stats"][i], ref, 13, f"rand{seed}-{i}")
+            check_stats(out["stats"][i], ref, K, f"rand{seed}-{i}")
             n_ok += 1
         assert n_ok >= 15
     finally:

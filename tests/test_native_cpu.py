@@ -94,16 +94,22 @@ def test_f0_host_tables_match_the_pyin_oracle():
 
 
 @pytest.mark.parametrize("sr,n_fft,n_mels", [(22050, 1024, 128), (22050, 1024, 40), (22050, 1024, 64), (16000, 1024, 128),
-                                               (44100, 1024, 256), (8000, 1024, 20)])
+                                               (44100, 1024, 256), (8000, 1024, 20),
+                                               (44100, 2048, 128), (22050, 2048, 40), (16000, 512, 128), (8000, 512, 40)])
 def test_wave_mel_schedule_reproduces_the_filterbank(sr, n_fft, n_mels):
-    """The per-lane tap schedule of k_frames3 is a re-ordering of librosa.filters.mel: summing every lane's
-    weights back onto (filter, bin) must give the dense float32 matrix exactly, every real filter must have
-    exactly one owner lane, first bins are even (16-byte reads), and a width-1 round must not put two
-    different read addresses on one LDS slot within a ds_read_b128 lane group."""
+    """The per-lane tap schedule of the wave-level frame kernels is a re-ordering of librosa.filters.mel: summing
+    every lane's weights back onto (filter, bin) must give the dense float32 matrix exactly, every real filter
+    must have exactly one owner lane per spectrum, first bins are aligned to the 16-byte reads (2 bins of a frame
+    pair at n_fft 1024 / 512, 4 bins of one frame at 2048), no padded tap leaves the LDS image, and at the
+    reference configurations a width-1 round puts no two different read addresses on one LDS slot within a
+    ds_read_b128 lane group.  n_fft 512: two spectra per wave, the upper half-wave repeats the lower one's schedule."""
     p = N.make_params(sr, n_fft, n_fft // 4, 13, n_mels)
     _, mel, _ = N.build_tables(p)
     s = N.build_mel_schedule(p)
     nbins = n_fft // 2 + 1
+    align = 4 if n_fft == 2048 else 2
+    lanes = 32 if n_fft == 512 else 64
+    max_slot = {1024: 1087, 2048: 2175, 512: 543}[n_fft]
     dense = np.zeros((n_mels, nbins + 64), np.float64)
     owners = np.zeros(n_mels, int)
     groups = [[0, 1, 2, 3, 12, 13, 14, 15] + list(range(20, 28)), list(range(4, 12)) + [16, 17, 18, 19, 28, 29, 30, 31],
@@ -111,23 +117,26 @@ def test_wave_mel_schedule_reproduces_the_filterbank(sr, n_fft, n_mels):
     for r in range(s["rounds"]):
         nb, wd = s["nb"][r], s["width"][r]
         w = s["weights"][s["woff"][r]: s["woff"][r] + nb * 256].reshape(nb, 64, 4)
-        for lane in range(64):
+        if lanes == 32:
+            np.testing.assert_array_equal(s["meta"][r, :32], s["meta"][r, 32:])
+            np.testing.assert_array_equal(w[:, :32], w[:, 32:])
+        for lane in range(lanes):
             meta = int(s["meta"][r, lane])
             bin0, m, own = meta & 2047, (meta >> 11) & 511, (meta >> 20) & 1
-            assert bin0 % 2 == 0
+            assert bin0 % align == 0
             taps = w[:, lane, :].reshape(-1)
             if own:
                 owners[m] += 1
             if taps.any():
                 assert m < n_mels
                 dense[m, bin0: bin0 + 4 * nb] += taps
-            assert bin0 + 4 * nb - 1 <= 1087
-        if wd == 1 and (sr, n_mels) == (22050, 128):       # the reference configuration: a perfect matching exists
-            for g in groups:
+            assert bin0 + 4 * nb - 1 <= max_slot
+        if wd == 1 and (sr, n_fft, n_mels) in ((22050, 1024, 128), (44100, 2048, 128)):     # a perfect matching exists there
+            for g in groups[: lanes // 16]:
                 slots = {}
                 for lane in g:
                     b0 = int(s["meta"][r, lane]) & 2047
-                    slots.setdefault((b0 // 2) % 16, set()).add(b0)
+                    slots.setdefault((b0 // align) % 16, set()).add(b0)
                 assert all(len(v) == 1 for v in slots.values()), (r, slots)
     assert (owners == 1).all()
     np.testing.assert_array_equal(dense[:, :nbins].astype(np.float32), mel)
