@@ -103,10 +103,41 @@ def to_mono(y: np.ndarray) -> np.ndarray:
     return np.mean(y.T, axis=0, dtype=np.float32)
 
 
+# Resampling policy (librosa.load(path, sr=...) at feature_extractor.py:52 resamples with
+# soxr_hq).  soxr is not available here and bit parity with it is not a goal -- "parity unpinned" -- so this states
+# what the engine's own resampler guarantees instead, and tests/test_wavio.py holds it to that:
+#   * output length ceil(n * sr_out / sr_in), librosa's rule (it fixes the length after any resampler);
+#   * a linear-phase Kaiser-windowed sinc low-pass (beta 12.98, ~125 dB) evaluated as a polyphase filter
+#     (scipy.signal.resample_poly with explicit taps), transition band 0.913 .. 1.0 of the lower rate's Nyquist -- the
+#     band edges soxr documents for its HQ recipe;
+#   * pass band (up to 0.9 x that Nyquist): gain within 1e-4 of unity; stop band (at and above it): below -100 dB;
+#   * float64 arithmetic, float32 result (librosa returns float32).
+_RESAMPLE_TAPS = {}
+
+
+def _resample_filter(up: int, down: int) -> np.ndarray:
+    key = (up, down)
+    h = _RESAMPLE_TAPS.get(key)
+    if h is None:
+        import scipy.signal
+        fs = float(up)                                      # internal rate in units of sr_in
+        nyq_low = 0.5 * min(1.0, up / down)                 # the lower of the two Nyquist frequencies, same units
+        width = (1.0 - 0.913) * nyq_low
+        numtaps, beta = scipy.signal.kaiserord(125.0, width / (0.5 * fs))
+        numtaps |= 1
+        h = scipy.signal.firwin(numtaps, 0.5 * (0.913 + 1.0) * nyq_low, window=("kaiser", beta), fs=fs)   # unity DC gain: resample_poly scales by up
+        _RESAMPLE_TAPS[key] = h
+    return h
+
+
 def resample(y: np.ndarray, sr_in: int, sr_out: int) -> np.ndarray:
+    """y at sr_in -> float32 at sr_out, ceil(n * sr_out / sr_in) samples (policy above)."""
     import scipy.signal
+    if int(sr_in) == int(sr_out):
+        return np.asarray(y, np.float32)
     g = gcd(int(sr_in), int(sr_out))
-    out = scipy.signal.resample_poly(y.astype(np.float64), sr_out // g, sr_in // g)
+    up, down = int(sr_out) // g, int(sr_in) // g
+    out = scipy.signal.resample_poly(np.asarray(y, np.float64), up, down, window=_resample_filter(up, down))
     n = int(np.ceil(y.shape[-1] * sr_out / sr_in))     # librosa fixes the length to ceil(n * ratio)
     out = out[:n] if out.shape[-1] >= n else np.pad(out, (0, n - out.shape[-1]))
     return out.astype(np.float32)

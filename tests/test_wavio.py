@@ -66,3 +66,48 @@ def test_bad_files_raise(tmp_path):
     _wav(tmp_path / "adpcm.wav", 2, 1, 8000, 4, b"\x00" * 16)
     with pytest.raises(ValueError):
         wavio.load(str(tmp_path / "adpcm.wav"), 8000)
+
+
+# ---- resampling policy (wavio.py): length rule, pass-band flatness, alias rejection -- the engine's own guarantees;
+# parity with librosa's soxr_hq is unpinned (soxr is not installable here)
+@pytest.mark.parametrize("sr_in,sr_out", [(44100, 22050), (48000, 22050), (16000, 22050), (8000, 22050), (22050, 16000),
+                                          (32000, 44100)])
+def test_resample_length_rule_and_passband(sr_in, sr_out):
+    for n in (1, 7, 1000, sr_in + 13):
+        assert wavio.resample(np.zeros(n, np.float32), sr_in, sr_out).size == int(np.ceil(n * sr_out / sr_in))
+    low_nyq = 0.5 * min(sr_in, sr_out)
+    t = np.arange(2 * sr_in) / sr_in
+    for frac in (0.02, 0.5, 0.9):                       # of the lower Nyquist: inside the pass band
+        f = frac * low_nyq
+        y = np.sin(2 * np.pi * f * t).astype(np.float32)
+        r = wavio.resample(y, sr_in, sr_out)
+        assert r.dtype == np.float32
+        tt = np.arange(r.size) / sr_out
+        mid = slice(sr_out // 2, r.size - sr_out // 2)   # away from the edges (the filter sees zeros beyond the clip)
+        ref = np.sin(2 * np.pi * f * tt)
+        assert np.abs(r[mid] - ref[mid]).max() < 2e-4, (sr_in, sr_out, frac)      # gain and phase: the filter is linear-phase, delay compensated
+
+
+@pytest.mark.parametrize("sr_in,sr_out", [(44100, 22050), (48000, 22050), (22050, 16000)])
+def test_resample_rejects_what_would_alias(sr_in, sr_out):
+    t = np.arange(2 * sr_in) / sr_in
+    for f in (0.5 * sr_out * 1.02, 0.5 * sr_out * 1.4, 0.45 * sr_in):      # above the new Nyquist
+        y = np.sin(2 * np.pi * f * t).astype(np.float32)
+        r = wavio.resample(y, sr_in, sr_out)
+        mid = slice(sr_out // 2, r.size - sr_out // 2)
+        assert np.sqrt(np.mean(r[mid].astype(np.float64) ** 2)) < 1e-5, (sr_in, sr_out, f)   # below -100 dB re the tone's 0.707 rms
+
+
+def test_resample_swept_sine_and_identity():
+    sr_in, sr_out = 44100, 22050
+    t = np.arange(4 * sr_in) / sr_in
+    f1 = 20000.0
+    y = np.sin(2 * np.pi * (f1 / (2 * t[-1])) * t * t).astype(np.float32)       # 0 -> 20 kHz over 4 s
+    r = wavio.resample(y, sr_in, sr_out).astype(np.float64)
+    n = r.size
+    early = r[n // 20: n // 4]                     # sweep below 5 kHz: passes
+    late = r[int(0.62 * n): int(0.95 * n)]         # sweep above 12.4 kHz: gone (new Nyquist 11025 Hz)
+    assert 0.69 < np.sqrt(np.mean(early ** 2)) < 0.72
+    assert np.sqrt(np.mean(late ** 2)) < 1e-4
+    same = wavio.resample(y, 22050, 22050)
+    assert same is y or np.array_equal(same, y)
