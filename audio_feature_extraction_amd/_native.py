@@ -42,6 +42,7 @@ class Params(C.Structure):
         ("trim_top_db", C.c_float), ("trim_frame", C.c_int32), ("trim_hop", C.c_int32),
         ("top_db", C.c_float), ("amin", C.c_float), ("delta_width", C.c_int32),
         ("reserved", C.c_int32),
+        ("fmin", C.c_float), ("fmax", C.c_float), ("htk", C.c_int32), ("lifter", C.c_float),
     ]
 
 
@@ -118,7 +119,7 @@ def device_count() -> int:
 
 
 def make_params(sr=22050, n_fft=1024, hop=256, n_mfcc=13, n_mels=128, window="hamming",
-                preemph=0.97) -> Params:
+                preemph=0.97, fmin=0.0, fmax=None, htk=False, lifter=0.0) -> Params:
     p = Params()
     lib().afx_default_params(C.byref(p))
     p.sr, p.n_fft, p.hop, p.n_mfcc, p.n_mels = int(sr), int(n_fft), int(hop), int(n_mfcc), int(n_mels)
@@ -127,6 +128,7 @@ def make_params(sr=22050, n_fft=1024, hop=256, n_mfcc=13, n_mels=128, window="ha
         raise ValueError(f"unsupported window {window!r} (hamming, hann)")
     p.window = wl[window]
     p.preemph = float(preemph)
+    p.fmin, p.fmax, p.htk, p.lifter = float(fmin), float(fmax or 0.0), int(bool(htk)), float(lifter)
     return p
 
 

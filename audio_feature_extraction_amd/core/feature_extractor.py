@@ -52,10 +52,17 @@ class AudioFeatureExtractor:
                  *,
                  window: str = "hamming",
                  n_mels: int = 128,
+                 fmin: float = 0.0,
+                 fmax: Optional[float] = None,
+                 htk: bool = False,
+                 lifter: float = 0.0,
                  device: Optional[Sequence[int] | int] = None):
         """Positional arguments are the reference's (feature_extractor.py:10-17).
         Keyword-only extensions default to the reference's hard-coded values:
-        ``window`` ('hamming', :133; 'hann' also supported), ``n_mels`` (librosa's 128),
+        ``window`` ('hamming', :133; 'hann' also supported), ``n_mels`` (librosa's 128), ``fmin`` / ``fmax`` /
+        ``htk`` (librosa.filters.mel's band edges and mel scale) and ``lifter`` (librosa.feature.mfcc's) -- the
+        variants the reference's experiment extractors pass (04_feature_extraction_experiment/
+        audio_feature_extraction 2/audio_feature_extraction/feature_extractor.py:148-181),
         ``device`` (GPU index or list of indices; None = all visible GPUs for
         ``batch_process``, GPU 0 for single-clip calls)."""
         self.sr = sr
@@ -67,6 +74,7 @@ class AudioFeatureExtractor:
         self.pre_emphasis = pre_emphasis
         self.window = window
         self.n_mels = n_mels
+        self.fmin, self.fmax, self.htk, self.lifter = fmin, fmax, htk, lifter
         self.device = device
 
         logging.basicConfig(level=logging.INFO)
@@ -94,7 +102,8 @@ class AudioFeatureExtractor:
             pl = self._plans.get((device, lane))
             if pl is None:
                 params = _native.make_params(self.sr, self.frame_length, self.hop_length, self.n_mfcc,
-                                             self.n_mels, self.window, self.pre_emphasis)
+                                             self.n_mels, self.window, self.pre_emphasis,
+                                             self.fmin, self.fmax, self.htk, self.lifter)
                 pl = _native.Plan(_native.Context(device), params)
                 self._plans[(device, lane)] = pl
             return pl

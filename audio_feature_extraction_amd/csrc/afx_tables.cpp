@@ -30,6 +30,9 @@ int validate_params(const afx_params& p, std::string& msg) {
       (p.trim_frame / p.trim_hop) % 2 != 0)
     return bad("trim_frame must be an even multiple of trim_hop");
   if (!(p.amin > 0.f)) return bad("amin must be positive");
+  if (!(p.fmin >= 0.f) || (p.fmax != 0.f && !(p.fmax > p.fmin)) || p.fmax > 0.5f * (float)p.sr + 1e-3f)
+    return bad("need 0 <= fmin < fmax <= sr / 2 (fmax = 0 means sr / 2)");
+  if (!(p.lifter >= 0.f)) return bad("lifter must be >= 0");
   bool pow2 = p.n_fft > 0 && (p.n_fft & (p.n_fft - 1)) == 0;
   if (!pow2 || p.n_fft < 256 || p.n_fft > 4096) {
     msg = "frame_length must be a power of two in [256, 4096]";
@@ -52,12 +55,14 @@ static double mel_to_hz(double m) {
 
 static void build_mel_dense(const afx_params& p, std::vector<float>& W, std::vector<double>& mel_f) {
   const int M = p.n_mels, NB = p.n_fft / 2 + 1;
-  const double fmax = (double)p.sr / 2.0;
-  // mel_frequencies(n_mels + 2): np.linspace in the mel domain
+  const double fmin = (double)p.fmin, fmax = p.fmax > 0.f ? (double)p.fmax : (double)p.sr / 2.0;
+  // mel_frequencies(n_mels + 2, fmin, fmax, htk): np.linspace in the mel domain (Slaney's scale, or HTK's 2595 log10(1 + f / 700))
+  auto to_mel = [&](double f) { return p.htk ? 2595.0 * std::log10(1.0 + f / 700.0) : hz_to_mel(f); };
+  auto to_hz = [&](double m) { return p.htk ? 700.0 * (std::pow(10.0, m / 2595.0) - 1.0) : mel_to_hz(m); };
   mel_f.assign(M + 2, 0.0);
-  const double m0 = hz_to_mel(0.0), m1 = hz_to_mel(fmax);
+  const double m0 = to_mel(fmin), m1 = to_mel(fmax);
   const double step = (m1 - m0) / (double)(M + 1);
-  for (int i = 0; i < M + 2; ++i) mel_f[i] = mel_to_hz(i == M + 1 ? m1 : (double)i * step + m0);
+  for (int i = 0; i < M + 2; ++i) mel_f[i] = to_hz(i == M + 1 ? m1 : (double)i * step + m0);
   W.assign((size_t)M * NB, 0.f);
   for (int i = 0; i < M; ++i) {
     const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
@@ -377,6 +382,11 @@ void build_host_tables(const afx_params& p, HostTables& t) {
     const double s = k == 0 ? std::sqrt(1.0 / M) : std::sqrt(2.0 / M);
     for (int m = 0; m < M; ++m)
       t.dct[(size_t)k * M + m] = (float)(s * std::cos(kPi * k * (2.0 * m + 1.0) / (2.0 * M)));
+    if (p.lifter > 0.f) {         // librosa.feature.mfcc(lifter=L): row n = k + 1 scaled by 1 + (L / 2) sin(pi n / L), folded into the DCT row
+      const float li = (float)std::sin(kPi * (double)(k + 1) / (double)p.lifter);
+      const float f = 1.0f + (p.lifter * 0.5f) * li;
+      for (int m = 0; m < M; ++m) t.dct[(size_t)k * M + m] *= f;
+    }
   }
   build_dct_blocks(p, t.dct, t.dctb);
   t.tw.resize((size_t)2 * N2); t.post.resize((size_t)2 * N2);
@@ -397,6 +407,7 @@ extern "C" void afx_default_params(afx_params* p) {
   p->window = AFX_WINDOW_HAMMING; p->preemph = 0.97f; p->trim_top_db = 30.f;
   p->trim_frame = 2048; p->trim_hop = 512; p->top_db = 80.f; p->amin = 1e-10f;
   p->delta_width = 9;
+  p->fmin = 0.f; p->fmax = 0.f; p->htk = 0; p->lifter = 0.f;
 }
 
 extern "C" int afx_build_mel_schedule(const afx_params* p, int32_t* info, float* weights, int32_t* meta) {

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AFX_VERSION 100
+#define AFX_VERSION 101
 
 typedef enum afx_status {
   AFX_OK = 0,
@@ -75,6 +75,13 @@ typedef struct afx_params {
   float   amin;          /* 1e-10 */
   int32_t delta_width;   /* 9, librosa.feature.delta default */
   int32_t reserved;
+  /* mel / MFCC option variants the reference's experiment extractors pass to librosa.filters.mel and
+   * librosa.feature.mfcc (04_feature_extraction_experiment/audio_feature_extraction 2/audio_feature_extraction/
+   * feature_extractor.py:148-181); the packaged class passes none, i.e. the defaults below */
+  float   fmin;          /* 0: lowest mel band edge, Hz */
+  float   fmax;          /* 0 = sr / 2: highest band edge, Hz */
+  int32_t htk;           /* 0: Slaney mel scale; 1: HTK formula */
+  float   lifter;        /* 0: none; L > 0: coefficient n (1-based) scaled by 1 + (L / 2) sin(pi n / L) */
 } afx_params;
 
 typedef struct afx_ctx afx_ctx;

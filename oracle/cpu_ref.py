@@ -187,18 +187,25 @@ def _mel_to_hz(mels):
     return freqs
 
 
-def mel_frequencies(n_mels: int, fmin: float, fmax: float) -> np.ndarray:
+def mel_frequencies(n_mels: int, fmin: float, fmax: float, htk: bool = False) -> np.ndarray:
+    """librosa.mel_frequencies: n_mels points evenly spaced in mel between fmin and fmax; htk=True uses the HTK
+    formula mel = 2595 log10(1 + f / 700) instead of Slaney's (the option the reference's older extractor passes,
+    04_feature_extraction_experiment/audio_feature_extraction 2/audio_feature_extraction/feature_extractor.py:148-155)."""
+    if htk:
+        lo = 2595.0 * np.log10(1.0 + np.float64(fmin) / 700.0)
+        hi = 2595.0 * np.log10(1.0 + np.float64(fmax) / 700.0)
+        return 700.0 * (10.0 ** (np.linspace(lo, hi, n_mels) / 2595.0) - 1.0)
     mels = np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels)
     return _mel_to_hz(mels)
 
 
 def mel_filterbank(sr: float, n_fft: int, n_mels: int = 128, fmin: float = 0.0,
-                   fmax: float | None = None) -> np.ndarray:
-    if fmax is None:
+                   fmax: float | None = None, htk: bool = False) -> np.ndarray:
+    if fmax is None or fmax <= 0:
         fmax = float(sr) / 2
     weights = np.zeros((n_mels, 1 + n_fft // 2), dtype=np.float32)
     fftfreqs = np.fft.rfftfreq(n=n_fft, d=1.0 / sr)
-    mel_f = mel_frequencies(n_mels + 2, fmin=fmin, fmax=fmax)
+    mel_f = mel_frequencies(n_mels + 2, fmin=fmin, fmax=fmax, htk=htk)
     fdiff = np.diff(mel_f)
     ramps = np.subtract.outer(mel_f, fftfreqs)
     for i in range(n_mels):
@@ -210,9 +217,9 @@ def mel_filterbank(sr: float, n_fft: int, n_mels: int = 128, fmin: float = 0.0,
     return weights
 
 
-def melspectrogram(y, sr, n_fft, hop_length, window="hamming", n_mels=128):
+def melspectrogram(y, sr, n_fft, hop_length, window="hamming", n_mels=128, fmin=0.0, fmax=None, htk=False):
     S = np.abs(stft(y, n_fft, hop_length, window)) ** 2.0
-    basis = mel_filterbank(sr, n_fft, n_mels)
+    basis = mel_filterbank(sr, n_fft, n_mels, fmin, fmax, htk)
     if y.dtype == np.float64:
         basis = basis.astype(np.float64)
     return np.einsum("ft,mf->mt", S, basis, optimize=True)
@@ -233,9 +240,12 @@ def power_to_db(S, amin: float = 1e-10, top_db: float | None = 80.0):
 # A7  librosa.feature.mfcc -> scipy.fft.dct(type=2, norm='ortho')[:n_mfcc]
 # --------------------------------------------------------------------------
 def mfcc(y, sr, n_mfcc, n_fft, hop_length, window="hamming", n_mels=128,
-         top_db: float | None = 80.0, return_logmel: bool = False):
-    L = power_to_db(melspectrogram(y, sr, n_fft, hop_length, window, n_mels), top_db=top_db)
+         top_db: float | None = 80.0, return_logmel: bool = False, fmin=0.0, fmax=None, htk=False, lifter=0.0):
+    L = power_to_db(melspectrogram(y, sr, n_fft, hop_length, window, n_mels, fmin, fmax, htk), top_db=top_db)
     M = scipy.fft.dct(L, axis=-2, type=2, norm="ortho")[:n_mfcc, :]
+    if lifter > 0:          # librosa.feature.mfcc(lifter=...): M *= 1 + (lifter / 2) * sin(pi * n / lifter), n = 1..n_mfcc
+        LI = np.sin(np.pi * np.arange(1, 1 + n_mfcc, dtype=M.dtype) / lifter)
+        M = M * (1 + (lifter / 2) * LI).astype(M.dtype)[:, np.newaxis]
     return (M, L) if return_logmel else M
 
 
@@ -255,8 +265,8 @@ def delta(data, width: int = 9, order: int = 1):
 # A9/A10 per-method statistics                          (feature_extractor.py:116-179)
 # --------------------------------------------------------------------------
 def extract_mfcc(y, sr, n_mfcc, n_fft, hop_length, window="hamming", n_mels=128,
-                 return_frames: bool = False):
-    M = mfcc(y, sr, n_mfcc, n_fft, hop_length, window, n_mels)
+                 return_frames: bool = False, fmin=0.0, fmax=None, htk=False, lifter=0.0):
+    M = mfcc(y, sr, n_mfcc, n_fft, hop_length, window, n_mels, fmin=fmin, fmax=fmax, htk=htk, lifter=lifter)
     d1 = delta(M)
     d2 = delta(M, order=2)
     out = {
@@ -300,7 +310,7 @@ def zero_crossing_rate(y: np.ndarray, frame_length: int = 2048, hop_length: int 
 
 def extract_stats(y_raw, sr=22050, frame_length=1024, hop_length=256, n_mfcc=13,
                   pre_emphasis=0.97, window="hamming", n_mels=128,
-                  dtype=np.float32, return_frames: bool = False):
+                  dtype=np.float32, return_frames: bool = False, fmin=0.0, fmax=None, htk=False, lifter=0.0):
     """preprocess_audio -> extract_mfcc + extract_energy, as extract_features
     does (feature_extractor.py:193-199) minus file load and pYIN.  Returns a
     dict of numpy values (statistics; per-frame arrays when return_frames)."""
@@ -308,7 +318,7 @@ def extract_stats(y_raw, sr=22050, frame_length=1024, hop_length=256, n_mfcc=13,
     y_proc, (start, end) = preprocess_audio(y, coef=pre_emphasis)
     out = {"trim": (start, end)}
     out.update(extract_mfcc(y_proc, sr, n_mfcc, frame_length, hop_length, window,
-                            n_mels, return_frames=return_frames))
+                            n_mels, return_frames=return_frames, fmin=fmin, fmax=fmax, htk=htk, lifter=lifter))
     out.update(extract_energy(y_proc, frame_length, hop_length, return_frames=return_frames))
     if return_frames:
         out["y_processed"] = y_proc

@@ -79,6 +79,29 @@ def test_per_frame_and_stats_parity(plans, name):
         assert e_gpu <= max(4 * e_ref, 2e-5), f"{what}: gpu {e_gpu:.2e} vs oracle-f32 {e_ref:.2e}"
 
 
+@pytest.mark.parametrize("sr,n_fft,hop,K,n_mels,opt", [
+    (22050, 1024, 256, 13, 40, dict(fmin=80.0, fmax=8000.0, htk=True, lifter=22.0)),     # the older extractor's options
+    (16000, 512, 128, 13, 24, dict(fmin=0.0, fmax=8000.0, htk=True, lifter=0.0)),
+    (44100, 2048, 512, 20, 64, dict(fmin=30.0, fmax=16000.0, htk=False, lifter=40.0)),
+    (8000, 256, 64, 13, 40, dict(fmin=100.0, fmax=3800.0, htk=True, lifter=22.0)),        # generic kernel
+])
+def test_mel_and_mfcc_option_variants(ctx, sr, n_fft, hop, K, n_mels, opt):
+    """fmin / fmax / htk / lifter (04_feature_extraction_experiment/audio_feature_extraction 2/audio_feature_extraction/
+    feature_extractor.py:148-181) through every frame kernel."""
+    plan = N.Plan(ctx, N.make_params(sr, n_fft, hop, K, n_mels, "hamming", 0.97, **opt))
+    try:
+        for idx, speechy in ((21, False), (22, True)):
+            y = make_clip(idx, sr, 1.5, speechy=speechy)
+            out = run_one(plan, y)
+            assert out["status"][0] == 0
+            ref = R.extract_stats(y, sr=sr, frame_length=n_fft, hop_length=hop, n_mfcc=K, n_mels=n_mels, return_frames=True, **opt)
+            assert tuple(out["trim"][0]) == ref["trim"]
+            check_frames(out["frames"][0], ref, f"opt {sr}/{n_fft} clip{idx}")
+            check_stats(out["stats"][0], ref, K, f"opt {sr}/{n_fft} clip{idx}")
+    finally:
+        plan.close()
+
+
 def test_config1_five_second_clip(plans):
     y = make_clip(0, 22050, 5.0)
     out = run_one(plans("cfg2"), y)

@@ -32,7 +32,8 @@ def test_params_struct_matches_header_layout():
     assert p.window == N.WINDOW_HAMMING and p.preemph == pytest.approx(0.97)
     assert (p.trim_top_db, p.trim_frame, p.trim_hop) == (30.0, 2048, 512)
     assert (p.top_db, p.delta_width) == (80.0, 9) and p.amin == pytest.approx(1e-10)
-    assert ctypes.sizeof(N.Params) == 56
+    assert ctypes.sizeof(N.Params) == 72
+    assert (p.fmin, p.fmax, p.htk, p.lifter) == (0.0, 0.0, 0, 0.0)          # the packaged class passes none of them
 
 
 @pytest.mark.parametrize("sr,n_fft,n_mfcc,window", [(22050, 1024, 13, "hamming"), (16000, 512, 40, "hamming"),
@@ -141,3 +142,31 @@ def test_wave_mel_schedule_reproduces_the_filterbank(sr, n_fft, n_mels):
     assert (owners == 1).all()
     np.testing.assert_array_equal(dense[:, :nbins].astype(np.float32), mel)
     assert not dense[:, nbins:].any()
+
+
+@pytest.mark.parametrize("sr,n_fft,n_mels,fmin,fmax,htk", [(22050, 1024, 40, 80.0, 8000.0, True), (16000, 512, 24, 0.0, 8000.0, True),
+                                                          (22050, 1024, 128, 50.0, 7600.0, False), (44100, 2048, 64, 20.0, None, False)])
+def test_mel_option_variants_match_the_oracle_bit_for_bit(sr, n_fft, n_mels, fmin, fmax, htk):
+    """fmin / fmax / htk as the reference's older extractor passes them (04_feature_extraction_experiment/
+    audio_feature_extraction 2/audio_feature_extraction/feature_extractor.py:148-155)."""
+    p = N.make_params(sr, n_fft, n_fft // 4, 13, n_mels, fmin=fmin, fmax=fmax, htk=htk)
+    _, mel, _ = N.build_tables(p)
+    np.testing.assert_array_equal(mel, R.mel_filterbank(sr, n_fft, n_mels, fmin, fmax, htk))
+    # HTK known answers: mel(700 Hz) = 2595 log10(2), and the band edges are evenly spaced on that scale
+    if htk:
+        assert abs(2595.0 * np.log10(2.0) - 781.17284) < 1e-4           # mel(700 Hz) on the HTK scale
+        f = R.mel_frequencies(n_mels + 2, fmin, fmax, htk=True)
+        m = 2595.0 * np.log10(1.0 + f / 700.0)
+        np.testing.assert_allclose(np.diff(m), np.diff(m)[0], rtol=1e-9)
+    with pytest.raises(ValueError):
+        N.build_tables(N.make_params(sr, n_fft, n_fft // 4, 13, n_mels, fmin=4000.0, fmax=3000.0))
+
+
+def test_lifter_scales_the_dct_rows():
+    p0 = N.make_params(22050, 1024, 256, 13, 40)
+    p1 = N.make_params(22050, 1024, 256, 13, 40, lifter=22.0)
+    d0, d1 = N.build_tables(p0)[2], N.build_tables(p1)[2]
+    n = np.arange(1, 14, dtype=np.float32)
+    f = (1 + (22.0 / 2) * np.sin(np.pi * n / 22.0)).astype(np.float32)      # librosa.feature.mfcc(lifter=22)
+    np.testing.assert_allclose(d1, d0 * f[:, None], rtol=2e-7)
+    assert f[0] > 1.5 and abs(f[10] - (1 + 11 * np.sin(np.pi * 11 / 22))) < 1e-5      # n = 11 = L / 2: factor 1 + L / 2

@@ -24,8 +24,8 @@ def kernel_stats(d):
 
 
 def short(k):
-    k = k.split("afx::")[-1] if "afx::" in k else k
-    return k.split("(")[0][:40]
+    k = k.split("afx::", 1)[1] if "afx::" in k else k
+    return k.split("(")[0][:48]
 
 
 for cfg in (2, 3, 5):
@@ -56,33 +56,27 @@ for cfg in (2, 3, 5):
     print("\n".join(lines))
     # traffic: FETCH_SIZE / WRITE_SIZE are in KB per dispatch; gfx950: FETCH_SIZE counts half the bytes of wide coalesced reads
     frames, hop = ALGO[cfg]
-    per_kernel, total = {}, 0.0
+    per_kernel = {}
     for k in acc:
         if "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
             fe = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"]) * 1024 * 2
             wr = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024
-            launches = 2 if k.startswith("k_frames3") else 1          # speculative + redo launch per step
-            per_kernel[k] = {"fetch_bytes_x2": fe, "write_bytes": wr, "per_dispatch": True}
-            total += (fe + wr) * (1 if not k.startswith("k_frames3") else 1)
+            per_kernel[k] = {"fetch_bytes_x2": fe, "write_bytes": wr}
     algo = frames * 4.0 * hop
-    frame_k = [k for k in per_kernel if k.startswith("k_frames")]
     tj = {"round": 2, "config": cfg,
-          "source": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/profile_r2.sh), single stream: one launch of every kernel per step"
-                    " (k_frames3*: the per-dispatch average is over the speculative launch and the near-empty redo launch; x2 launches per step)",
+          "source": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/profile_r2.sh), single stream: one launch of every kernel per step",
           "correction": "gfx950: FETCH_SIZE counts half the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact; KB -> bytes",
-          "per_kernel_bytes_per_dispatch": per_kernel,
+          "per_kernel_bytes_per_launch": per_kernel,
           "algorithmic_bytes_per_step": algo}
-    pipe = 0.0
-    for k, v in per_kernel.items():
-        mult = 2 if k.startswith("k_frames3") else 1
-        pipe += (v["fetch_bytes_x2"] + v["write_bytes"]) * mult
+    pipe = sum(v["fetch_bytes_x2"] + v["write_bytes"] for v in per_kernel.values())
     tj["pipeline_hbm_bytes_per_step"] = pipe
     tj["pipeline_over_algorithmic"] = pipe / algo
+    frame_k = [k for k in per_kernel if k.startswith("k_frames") and ("true>" in k or not k.startswith("k_frames3"))]
     if frame_k:
         v = per_kernel[frame_k[0]]
-        mult = 2 if frame_k[0].startswith("k_frames3") else 1
         tj["frame_kernel"] = frame_k[0]
-        tj["frame_kernel_hbm_bytes_per_step"] = (v["fetch_bytes_x2"] + v["write_bytes"]) * mult
+        tj["frame_kernel_hbm_bytes_per_step"] = v["fetch_bytes_x2"] + v["write_bytes"]
+        tj["frame_kernel_over_algorithmic"] = tj["frame_kernel_hbm_bytes_per_step"] / algo
     with open(os.path.join(root, f"cfg{cfg}_traffic.json"), "w") as fh:
         json.dump(tj, fh, indent=1)
     print(json.dumps({k: tj[k] for k in ("pipeline_hbm_bytes_per_step", "algorithmic_bytes_per_step", "pipeline_over_algorithmic")}))
