@@ -27,7 +27,7 @@ SYMBOLS = (
     "afx_version", "afx_device_count", "afx_last_error", "afx_init", "afx_destroy",
     "afx_malloc", "afx_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
     "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables", "afx_build_mel_schedule",
-    "afx_extract_batch", "afx_f0_batch", "afx_zcr_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings", "afx_plan_get_intervals",
+    "afx_extract_batch", "afx_f0_batch", "afx_zcr_batch", "afx_spectral_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings", "afx_plan_get_intervals",
 )
 
 
@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
         L.afx_extract_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
         L.afx_f0_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
         L.afx_zcr_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp]
+        L.afx_spectral_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp]
         L.afx_f0_build_tables.argtypes = [i32, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
         L.afx_preprocess.argtypes = [vp, vp, C.c_int64, vp, i64p, i64p, i32p]
         L.afx_plan_set_timing.argtypes = [vp, i32]
@@ -349,6 +350,32 @@ class Plan:
                                    lengths.ctypes.data, n, int(flags), z.ctypes.data, zoffs.ctypes.data,
                                    status.ctypes.data), "afx_zcr_batch")
         return {"zcr_flat": z, "zcr_offsets": zoffs, "status": status}
+
+    def spectral_batch(self, samples, offsets, lengths, flags=0, fmt=FMT_F32):
+        """Frame-level spectral descriptors of a ragged host batch (plan: frame_length 2048, hop_length 512).  Returns per
+        clip a dict: centroid / bandwidth / rolloff (T,) float32, valley / peak (7, T) float32 (spectral_contrast's band
+        extremes before the dB difference)."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        lengths = np.ascontiguousarray(lengths, np.int64)
+        n = int(offsets.shape[0])
+        want = np.int16 if fmt == FMT_S16 else np.float32
+        if not isinstance(samples, np.ndarray) or samples.dtype != want or not samples.flags.c_contiguous:
+            raise ValueError(f"samples must be a C-contiguous {want.__name__} array")
+        T = 1 + lengths // self.params.hop
+        doffs = np.zeros(n, np.int64)
+        if n:
+            doffs[1:] = np.cumsum(17 * T)[:-1]
+        d = np.zeros(int((17 * T).sum()) if n else 0, np.float32)
+        status = np.zeros(n, np.int32)
+        _check(lib().afx_spectral_batch(self.handle, samples.ctypes.data, int(fmt), MEM_HOST, offsets.ctypes.data,
+                                        lengths.ctypes.data, n, int(flags), d.ctypes.data, doffs.ctypes.data,
+                                        status.ctypes.data), "afx_spectral_batch")
+        out = []
+        for i in range(n):
+            m = d[doffs[i]: doffs[i] + 17 * T[i]].reshape(int(T[i]), 17)
+            out.append({"centroid": m[:, 0].copy(), "bandwidth": m[:, 1].copy(), "rolloff": m[:, 2].copy(),
+                        "valley": m[:, 3:10].T.copy(), "peak": m[:, 10:17].T.copy()})
+        return {"clips": out, "status": status}
 
     def preprocess(self, y: np.ndarray):
         y = np.ascontiguousarray(y, np.float32)

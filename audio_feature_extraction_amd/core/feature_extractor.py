@@ -245,6 +245,43 @@ class AudioFeatureExtractor:
             "zcr": zcr["zcr_flat"][:T].copy(),
         }
 
+    # ------------------------------------------------------------------ sibling frame features
+    def _spectral_plan(self) -> _native.Plan:
+        """librosa's defaults for the spectral descriptors: n_fft 2048, hop 512, Hann -- a plan of its own."""
+        device = self._devices()[0]
+        with self._plan_lock:
+            pl = self._plans.get((device, "spectral"))
+            if pl is None:
+                pl = _native.Plan(_native.Context(device), _native.make_params(self.sr, 2048, 512, 13, 128, "hann", self.pre_emphasis))
+                self._plans[(device, "spectral")] = pl
+            return pl
+
+    def extract_spectral_frames(self, y: np.ndarray) -> Dict[str, np.ndarray]:
+        """Frame-level ``librosa.feature.spectral_centroid / spectral_bandwidth / spectral_rolloff / spectral_contrast`` of
+        a signal at librosa's defaults, as the reference's experiment extractor calls them
+        (04_feature_extraction_experiment/feature_extractor.py:497-506): STFT, moments, roll-off search and the band
+        extremes of the contrast on the GPU; the contrast's dB difference with its clip-global ``top_db`` on the host."""
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        out = self._spectral_plan().spectral_batch(y, np.zeros(1, np.int64), np.array([y.size], np.int64))
+        if out["status"][0] != _native.CLIP_OK:
+            raise _status_error(int(out["status"][0]), "extract_spectral_features")
+        d = out["clips"][0]
+
+        def power_to_db(S):            # librosa.power_to_db(ref=1.0, amin=1e-10, top_db=80.0) of the whole matrix
+            L = 10.0 * np.log10(np.maximum(1e-10, S.astype(np.float64)))
+            return np.maximum(L, L.max() - 80.0)
+        return {"spectral_centroid": d["centroid"], "spectral_bandwidth": d["bandwidth"], "spectral_rolloff": d["rolloff"],
+                "spectral_contrast": power_to_db(d["peak"]) - power_to_db(d["valley"])}
+
+    def extract_spectral_features(self, y: np.ndarray) -> Dict[str, Any]:
+        """提取頻譜特徵: the eight statistics of 04_feature_extraction_experiment/feature_extractor.py:509-518."""
+        f = self.extract_spectral_frames(y)
+        out: Dict[str, Any] = {}
+        for k in ("spectral_centroid", "spectral_bandwidth", "spectral_rolloff", "spectral_contrast"):
+            out[k + "_mean"] = float(np.mean(f[k]))
+            out[k + "_std"] = float(np.std(f[k]))
+        return out
+
     @staticmethod
     def save_frame_features(features: Dict[str, np.ndarray], npz_path: str) -> None:
         """``np.savez(npz_path, **features)`` -- the reference's on-disk schema for frame-level features."""

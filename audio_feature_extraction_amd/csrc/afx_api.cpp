@@ -842,6 +842,85 @@ extern "C" int afx_zcr_batch(afx_plan* pl, const void* samples, int sample_fmt, 
   return AFX_OK;
 }
 
+// ---- spectral descriptors (librosa.feature.spectral_centroid / _bandwidth / _rolloff / _contrast at their defaults) ------
+extern "C" int afx_spectral_batch(afx_plan* pl, const void* samples, int sample_fmt, int mem_kind,
+                                  const int64_t* offsets, const int64_t* lengths, int n_clips, int flags,
+                                  float* out_desc, const int64_t* desc_offsets, int32_t* out_status) {
+  if (!pl || !offsets || !lengths || !out_desc || !desc_offsets || !out_status || n_clips < 0 || (!samples && n_clips > 0)) {
+    set_error("afx_spectral_batch: null/invalid argument");
+    return AFX_ERR_INVALID;
+  }
+  if (sample_fmt != AFX_FMT_F32 && sample_fmt != AFX_FMT_S16) { set_error("unknown sample format"); return AFX_ERR_INVALID; }
+  if (mem_kind != AFX_MEM_HOST && mem_kind != AFX_MEM_DEVICE) { set_error("unknown mem_kind"); return AFX_ERR_INVALID; }
+  if (pl->p.n_fft != 2048 || pl->p.hop != 512 || !pl->use_f3) {
+    set_error("afx_spectral_batch: the plan must have frame_length 2048 and hop_length 512 (librosa's defaults for these features)");
+    return AFX_ERR_UNSUPPORTED;
+  }
+  if (flags & AFX_FLAG_TRIM) { set_error("afx_spectral_batch: trim is not applied here; pass the preprocessed signal"); return AFX_ERR_UNSUPPORTED; }
+  if (n_clips == 0) return AFX_OK;
+  if (n_clips > 32768) { set_error("afx_spectral_batch: at most 32768 clips per call"); return AFX_ERR_INVALID; }
+  // octave bands of librosa.feature.spectral_contrast(fmin=200, n_bands=6, quantile=0.02) as bin ranges
+  SpecBands sb{};
+  {
+    const int NB = 1025;
+    const double sr = (double)pl->p.sr, df = sr / 2048.0;
+    double octa[8];
+    octa[0] = 0.0;
+    for (int i = 1; i < 8; ++i) octa[i] = 200.0 * std::pow(2.0, (double)(i - 1));
+    for (int i = 0; i < 7; ++i)
+      if (octa[i] >= 0.5 * sr) { set_error("spectral_contrast: frequency band exceeds Nyquist (sr too low for 6 octave bands from 200 Hz)"); return AFX_ERR_UNSUPPORTED; }
+    for (int k = 0; k < 7; ++k) {
+      int b0 = -1, b1 = -1;
+      for (int b = 0; b < NB; ++b) { const double f = (double)b * df; if (f >= octa[k] && f <= octa[k + 1]) { if (b0 < 0) b0 = b; b1 = b; } }
+      if (b0 < 0) { set_error("spectral_contrast: empty band"); return AFX_ERR_UNSUPPORTED; }
+      if (k > 0) b0 -= 1;
+      if (k == 6) b1 = NB - 1;
+      const int n_cur = b1 - b0 + 1;
+      sb.cnt[k] = std::max(1, (int)std::nearbyint(0.02 * (double)n_cur));
+      sb.lo[k] = b0; sb.hi[k] = (k < 6) ? b1 - 1 : b1;
+    }
+    sb.hz_per_bin = (float)df; sb.roll_percent = 0.85f;
+  }
+  (void)hipGetLastError();
+  HIP_TRY(hipSetDevice(pl->device));
+  hipStream_t s = pl->ctx->stream;
+  const int n = n_clips;
+  int rc;
+  const void* d_samples = samples;
+  if (mem_kind == AFX_MEM_HOST) {
+    const size_t esz = sample_fmt == AFX_FMT_S16 ? 2 : 4;
+    int64_t hi = 0;
+    for (int i = 0; i < n; ++i) hi = std::max(hi, offsets[i] + lengths[i]);
+    if ((rc = ensure(pl->samples, (size_t)hi * esz + 16)) != AFX_OK) return rc;
+    if (hi > 0) HIP_TRY(hipMemcpyAsync(pl->samples.p, samples, (size_t)hi * esz, hipMemcpyHostToDevice, s));
+    d_samples = pl->samples.p;
+  }
+  if ((rc = prepare_descriptors(pl, offsets, lengths, n)) != AFX_OK) return rc;
+  int64_t d_lo = INT64_MAX, d_hi = 0;
+  std::vector<int64_t> rebased(n);
+  for (int i = 0; i < n; ++i) {
+    if (desc_offsets[i] < 0) { set_error("negative descriptor offset"); return AFX_ERR_INVALID; }
+    d_lo = std::min(d_lo, desc_offsets[i]);
+    d_hi = std::max(d_hi, desc_offsets[i] + (int64_t)kSpecFloats * pl->h_clips[i].tmax);
+  }
+  for (int i = 0; i < n; ++i) rebased[i] = desc_offsets[i] - d_lo;
+  if ((rc = ensure(pl->info, n * sizeof(ClipInfo))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->frames, (size_t)(d_hi - d_lo) * sizeof(float))) != AFX_OK) return rc;
+  if ((rc = ensure(pl->frame_offs, n * sizeof(int64_t))) != AFX_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(pl->frame_offs.p, rebased.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(pl->frames.p, 0, (size_t)(d_hi - d_lo) * sizeof(float), s));
+  HIP_TRY(hipMemsetAsync(pl->info.p, 0, n * sizeof(ClipInfo), s));
+  KParams kp = pl->kp;
+  kp.flags = flags; kp.fmt = sample_fmt;
+  if (pl->nblocks > 0)
+    HIP_TRY(launch_spectral(s, d_samples, (ClipInfo*)pl->info.p, (const BlockDesc*)pl->blocks_spec.p, pl->nblocks, pl->f3, kp,
+                            (float*)pl->frames.p, (const int64_t*)pl->frame_offs.p, sb, pl->n_cu));
+  HIP_TRY(hipMemcpyAsync(out_desc + d_lo, pl->frames.p, (size_t)(d_hi - d_lo) * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i) out_status[i] = lengths[i] < 2 ? AFX_CLIP_TOO_SHORT : AFX_CLIP_OK;
+  return AFX_OK;
+}
+
 extern "C" int afx_preprocess(afx_plan* pl, const float* y, int64_t n, float* out_y,
                               int64_t* start, int64_t* end, int32_t* status) {
   if (!pl || !y || !out_y || !start || !end || !status || n < 0) {

@@ -63,6 +63,16 @@ hipError_t launch_frames3s(hipStream_t s, const void* samples, ClipInfo* info, c
 hipError_t launch_frames3d(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                            const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
                            float* blockmax, float* bsum, bool spec, int n_cu);
+// spectral descriptors (k_frames3s<DESC>): librosa.feature.spectral_contrast's octave bands as bin ranges [lo, hi] of the
+// sub-band and the number of magnitudes averaged at either end
+struct SpecBands {
+  int32_t lo[8], hi[8], cnt[8];
+  float hz_per_bin, roll_percent;
+};
+constexpr int kSpecFloats = 17;            // per frame: centroid, bandwidth, rolloff, valley[7], peak[7]
+hipError_t launch_spectral(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
+                           const F3Tables& ft, const KParams& kp, float* desc_out, const int64_t* desc_offs,
+                           const SpecBands& sb, int n_cu);
 // dispatch on kp.n_fft
 hipError_t launch_frames3_any(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                               const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,

@@ -29,7 +29,13 @@ size_t frames3s_lds_bytes(int waves, const F3Tables& ft) {
   return (size_t)(waves * kF3ExFloats + kF3sTabFloats + ft.mel_wfloats + ft.mel_rounds * 64) * sizeof(float);
 }
 
-template <int FMT, int WAVES, bool SPEC>
+// DESC: instead of the mel / dB stage, the frame-level spectral descriptors the reference's experiment extractor takes
+// from librosa at its defaults (n_fft 2048, hop 512: exactly this kernel's shape;
+// 04_feature_extraction_experiment/feature_extractor.py:497-506) off the magnitude spectrum sqrt(P) in the image:
+// spectral_centroid, spectral_bandwidth (p = 2, normalised), spectral_rolloff (85 %), and per octave band of
+// spectral_contrast the mean of the `cnt` largest and smallest magnitudes (peak / valley; the dB difference and its
+// clip-global top_db clamp are taken on the host).  17 floats per frame at desc_out[desc_offs[clip] + 17 t].
+template <int FMT, int WAVES, bool SPEC, bool DESC>
 __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict__ samples,
                                                          ClipInfo* __restrict__ info,
                                                          const BlockDesc* __restrict__ blocks, int nblocks,
@@ -37,7 +43,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
                                                          F3Tables ft, KParams kp,
                                                          float* __restrict__ logmel,
                                                          float* __restrict__ blockmax,
-                                                         float* __restrict__ bsum) {
+                                                         float* __restrict__ bsum,
+                                                         float* __restrict__ desc_out,
+                                                         const int64_t* __restrict__ desc_offs,
+                                                         SpecBands sb) {
   constexpr int N = 2048, HOP = 512;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -243,6 +252,87 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
           nx0[i] = row_ld(sp + jn, 128 * i + 2 * lane); nx1[i] = row_ld(sp + jn, 128 * i + 2 * lane + 1); nxp[i] = row_ld(sp + jn - 1, 128 * i + 2 * lane);
         }
       }
+      if constexpr (DESC) {
+        // ---- spectral descriptors: lane l holds the magnitudes of bins 16 l .. 16 l + 15 (lane 63 also bin 1024)
+        float mg[17];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 p4 = *reinterpret_cast<const float4*>(XB + 16 * lane + 4 * q);
+          mg[4 * q] = sqrtf(p4.x); mg[4 * q + 1] = sqrtf(p4.y); mg[4 * q + 2] = sqrtf(p4.z); mg[4 * q + 3] = sqrtf(p4.w);
+        }
+        mg[16] = lane == 63 ? sqrtf(XB[1024]) : 0.f;
+        auto wsum = [&](float q) -> float {
+          q += F3_DPP(q, 0xB1); q += F3_DPP(q, 0x4E); q += F3_DPP(q, 0x141); q += F3_DPP(q, 0x140);
+          const int qi = __float_as_int(q);
+          return (__int_as_float(__builtin_amdgcn_readlane(qi, 0)) + __int_as_float(__builtin_amdgcn_readlane(qi, 16))) +
+                 (__int_as_float(__builtin_amdgcn_readlane(qi, 32)) + __int_as_float(__builtin_amdgcn_readlane(qi, 48)));
+        };
+        const float hz = sb.hz_per_bin, k0f = (float)(16 * lane);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 17; ++j) { s0 += mg[j]; s1 = fmaf(mg[j], (k0f + (float)j) * hz, s1); }
+        const float tot = wsum(s0);
+        const float len = tot < 1.17549435e-38f ? 1.0f : tot;            // librosa.util.normalize(norm=1): a column below tiny keeps its scale
+        const float cen = wsum(s1) / len;
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 17; ++j) { const float d = (k0f + (float)j) * hz - cen; s2 = fmaf(mg[j], d * d, s2); }
+        const float bw = sqrtf(wsum(s2) / len);
+        // roll-off: lowest bin whose running sum reaches 85 % of the total (lane totals scanned across the wave)
+        float run[17], acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 17; ++j) { acc += mg[j]; run[j] = acc; }
+        float pre = acc;                                   // inclusive scan of lane totals
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(pre, o); if (lane >= o) pre += t; }
+        const float base = pre - acc, thr = sb.roll_percent * tot;
+        int kroll = 1 << 20;
+#pragma unroll
+        for (int j = 16; j >= 0; --j) if ((j < 16 || lane == 63) && base + run[j] >= thr) kroll = 16 * lane + j;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(kroll, o); kroll = t < kroll ? t : kroll; }
+        const float roll = (kroll < (1 << 20) ? (float)kroll : 0.f) * hz;
+        float* const dst = desc_out + desc_offs[bd.clip] + (int64_t)(bd.t0 + f) * 17;
+        if (lane == 0) { dst[0] = cen; dst[1] = bw; dst[2] = roll; }
+        // contrast bands: repeated extraction of the band's smallest (largest) remaining magnitude
+#pragma unroll 1
+        for (int bnd = 0; bnd < 7; ++bnd) {
+          const int lo = sb.lo[bnd], hi = sb.hi[bnd], cnt = sb.cnt[bnd];
+          unsigned inb = 0;
+#pragma unroll
+          for (int j = 0; j < 17; ++j) { const int k = 16 * lane + j; if (k >= lo && k <= hi && (j < 16 || lane == 63)) inb |= 1u << j; }
+#pragma unroll 1
+          for (int side = 0; side < 2; ++side) {           // 0: valley (smallest), 1: peak (largest)
+            unsigned avail = inb;
+            float total = 0.f;
+#pragma unroll 1
+            for (int r = 0; r < cnt; ++r) {
+              float m = side ? -1.f : INFINITY;
+              int jm = 0;
+#pragma unroll
+              for (int j = 0; j < 17; ++j) {
+                const bool ok = (avail >> j) & 1u;
+                const bool better = ok && (side ? mg[j] > m : mg[j] < m);
+                m = better ? mg[j] : m; jm = better ? j : jm;
+              }
+              float w = m;
+              if (side) { w = fmaxf(w, F3_DPP(w, 0xB1)); w = fmaxf(w, F3_DPP(w, 0x4E)); w = fmaxf(w, F3_DPP(w, 0x141)); w = fmaxf(w, F3_DPP(w, 0x140)); }
+              else { w = fminf(w, F3_DPP(w, 0xB1)); w = fminf(w, F3_DPP(w, 0x4E)); w = fminf(w, F3_DPP(w, 0x141)); w = fminf(w, F3_DPP(w, 0x140)); }
+              const int wi = __float_as_int(w);
+              const float r0 = __int_as_float(__builtin_amdgcn_readlane(wi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(wi, 16));
+              const float r2 = __int_as_float(__builtin_amdgcn_readlane(wi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(wi, 48));
+              const float best = side ? fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)) : fminf(fminf(r0, r1), fminf(r2, r3));
+              const bool have = side ? m >= 0.f : m < INFINITY;      // the lane still had a candidate
+              const unsigned long long holders = __ballot(have && m == best);
+              if (holders == 0ull) break;                   // band exhausted
+              const int owner = __ffsll((long long)holders) - 1;
+              if (lane == owner) avail &= ~(1u << jm);
+              total += best;
+            }
+            if (lane == 0) dst[3 + 7 * side + bnd] = cnt > 0 ? total / (float)cnt : 0.f;     // [3..9] valley, [10..16] peak
+          }
+        }
+      } else {
       // ---- mel + dB: a lane walks 4 * nb consecutive bins of its filter, four per 16-byte read
       const bool vF = f < Tleft;
       float* const rowF = tile + (unsigned)(f * M);
@@ -273,6 +363,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
           if (vF) { rowF[m] = L; lmax = f3_max(lmax, L); }
         }
       }
+      }
 
       // ---- take in the next frame's 4 new rows (sub-block t0 + f + 2 of the clip)
       if (more) {
@@ -298,7 +389,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
       const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
       const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
       const float mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-      if constexpr (SPEC) { if (lane == 0) blockmax[b] = mx; }
+      if constexpr (DESC) { (void)mx; }
+      else if constexpr (SPEC) { if (lane == 0) blockmax[b] = mx; }
       else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx)); }
     }
   }
@@ -319,15 +411,42 @@ static hipError_t launch_frames3s_t(hipStream_t s, const void* samples, ClipInfo
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3s<FMT, WAVES, SPEC>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3s<FMT, WAVES, SPEC, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
   const int grid = std::max(1, std::min(n_cu, (nblocks + WAVES - 1) / WAVES));
-  hipLaunchKernelGGL((k_frames3s<FMT, WAVES, SPEC>), dim3(grid), dim3(WAVES * 64), frames3s_lds_bytes(WAVES, ft), s,
-                     samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum);
+  hipLaunchKernelGGL((k_frames3s<FMT, WAVES, SPEC, false>), dim3(grid), dim3(WAVES * 64), frames3s_lds_bytes(WAVES, ft), s,
+                     samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, nullptr, nullptr, SpecBands{});
   return hipGetLastError();
+}
+
+template <int FMT>
+static hipError_t launch_spectral_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
+                                    const F3Tables& ft, const KParams& kp, float* desc_out, const int64_t* desc_offs,
+                                    const SpecBands& sb, int n_cu) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3s<FMT, 12, false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  const int grid = std::max(1, std::min(n_cu, (nblocks + 11) / 12));
+  hipLaunchKernelGGL((k_frames3s<FMT, 12, false, true>), dim3(grid), dim3(12 * 64), frames3s_lds_bytes(12, ft), s,
+                     samples, info, blocks, nblocks, nullptr, ft, kp, nullptr, nullptr, nullptr, desc_out, desc_offs, sb);
+  return hipGetLastError();
+}
+
+hipError_t launch_spectral(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
+                           const F3Tables& ft, const KParams& kp, float* desc_out, const int64_t* desc_offs,
+                           const SpecBands& sb, int n_cu) {
+  if (kp.fmt == AFX_FMT_S16) return launch_spectral_t<AFX_FMT_S16>(s, samples, info, blocks, nblocks, ft, kp, desc_out, desc_offs, sb, n_cu);
+  return launch_spectral_t<AFX_FMT_F32>(s, samples, info, blocks, nblocks, ft, kp, desc_out, desc_offs, sb, n_cu);
 }
 
 hipError_t launch_frames3s(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,

@@ -182,6 +182,22 @@ int afx_zcr_batch(afx_plan* plan,
                   const int64_t* offsets, const int64_t* lengths, int n_clips, int flags,
                   double* out_zcr, const int64_t* zcr_offsets, int32_t* out_status);
 
+/* Frame-level spectral descriptors the reference's experiment extractor takes from librosa at its defaults
+ * (04_feature_extraction_experiment/feature_extractor.py:497-506: spectral_centroid, spectral_bandwidth,
+ * spectral_rolloff, spectral_contrast; n_fft 2048, hop 512, centred, magnitude spectrum) of the given clips
+ * (flags: AFX_FLAG_PREEMPH or 0; no trim -- pass the preprocessed signal, as the reference does).  The plan must have
+ * n_fft 2048 / hop 512 (the reference calls librosa with its default Hann window: create the plan with AFX_WINDOW_HANN).
+ *   out_desc  host float buffer: clip i has T_i = 1 + length_i / 512 rows of 17 floats at out_desc[desc_offsets[i] ..]:
+ *             centroid (Hz), bandwidth (Hz, p = 2), rolloff (Hz, 85 %), then per octave band k = 0..6 of
+ *             spectral_contrast(fmin = 200, n_bands = 6, quantile = 0.02) the valley[k] (mean of the smallest
+ *             magnitudes) and after those the peak[k]; contrast = power_to_db(peak) - power_to_db(valley) with
+ *             librosa's clip-global top_db clamp is left to the caller (it needs the maximum over the whole clip).
+ *   AFX_ERR_UNSUPPORTED when sr <= 12800 (librosa: "Frequency band exceeds Nyquist") or the plan has another shape. */
+int afx_spectral_batch(afx_plan* plan,
+                       const void* samples, int sample_fmt, int mem_kind,
+                       const int64_t* offsets, const int64_t* lengths, int n_clips, int flags,
+                       float* out_desc, const int64_t* desc_offsets, int32_t* out_status);
+
 /* Host-only (no device needed): the tables afx_f0_batch uploads, for inspection and tests.
  * info[8] = min_period, max_period, n_pitch_bins, band (transition half-width), candidate
  * capacity, lags kept, lags per lane, trough slots per lane.  beta[100] = Beta(2,18) mass of

@@ -308,6 +308,89 @@ def zero_crossing_rate(y: np.ndarray, frame_length: int = 2048, hop_length: int 
     return np.mean(z, axis=0)
 
 
+# --------------------------------------------------------------------------
+# Sibling frame-level features: librosa.feature.spectral_centroid / spectral_bandwidth /
+# spectral_rolloff / spectral_contrast at librosa's defaults, as the reference's experiment extractor calls them
+# (04_feature_extraction_experiment/feature_extractor.py:497-506): n_fft=2048, hop_length=512, window='hann',
+# center=True (zero padding), magnitude spectrogram.
+# --------------------------------------------------------------------------
+def _magnitude_spectrogram(y, n_fft=2048, hop_length=512, window="hann"):
+    return np.abs(stft(y, n_fft, hop_length, window))
+
+
+def _normalize_l1(S):
+    """librosa.util.normalize(S, norm=1, axis=-2): columns whose norm is below tiny keep their scale."""
+    length = np.sum(np.abs(S), axis=-2, keepdims=True)
+    tiny = np.finfo(S.dtype).tiny
+    length = np.where(length < tiny, 1.0, length).astype(S.dtype)
+    return S / length
+
+
+def spectral_centroid(y, sr, n_fft=2048, hop_length=512, window="hann"):
+    S = _magnitude_spectrogram(y, n_fft, hop_length, window)
+    freq = np.fft.rfftfreq(n_fft, 1.0 / sr)[:, None]
+    return np.sum(freq * _normalize_l1(S), axis=-2, keepdims=True)
+
+
+def spectral_bandwidth(y, sr, n_fft=2048, hop_length=512, window="hann", p=2):
+    S = _magnitude_spectrogram(y, n_fft, hop_length, window)
+    freq = np.fft.rfftfreq(n_fft, 1.0 / sr)[:, None]
+    cen = np.sum(freq * _normalize_l1(S), axis=-2, keepdims=True)
+    dev = np.abs(freq - cen)
+    return np.sum(_normalize_l1(S) * dev ** p, axis=-2, keepdims=True) ** (1.0 / p)
+
+
+def spectral_rolloff(y, sr, n_fft=2048, hop_length=512, window="hann", roll_percent=0.85):
+    S = _magnitude_spectrogram(y, n_fft, hop_length, window)
+    freq = np.fft.rfftfreq(n_fft, 1.0 / sr)[:, None]
+    total = np.cumsum(S, axis=-2)
+    threshold = roll_percent * total[-1]
+    ind = np.where(total < threshold, np.nan, 1)
+    return np.nanmin(ind * freq, axis=-2, keepdims=True)
+
+
+def spectral_contrast_parts(y, sr, n_fft=2048, hop_length=512, window="hann", fmin=200.0, n_bands=6, quantile=0.02):
+    """(peak, valley), each (n_bands + 1, T): the band extremes librosa.feature.spectral_contrast averages."""
+    S = _magnitude_spectrogram(y, n_fft, hop_length, window)
+    freq = np.fft.rfftfreq(n_fft, 1.0 / sr)
+    octa = np.zeros(n_bands + 2)
+    octa[1:] = fmin * (2.0 ** np.arange(0, n_bands + 1))
+    if np.any(octa[:-1] >= 0.5 * sr):
+        raise ValueError("Frequency band exceeds Nyquist. Reduce either fmin or n_bands.")
+    valley = np.zeros((n_bands + 1, S.shape[1]))
+    peak = np.zeros_like(valley)
+    for k, (f_low, f_high) in enumerate(zip(octa[:-1], octa[1:])):
+        current_band = np.logical_and(freq >= f_low, freq <= f_high)
+        idx = np.flatnonzero(current_band)
+        if k > 0:
+            current_band[idx[0] - 1] = True
+        if k == n_bands:
+            current_band[idx[-1] + 1:] = True
+        sub_band = S[current_band]
+        if k < n_bands:
+            sub_band = sub_band[:-1]
+        idx = int(np.maximum(np.rint(quantile * np.sum(current_band)), 1))
+        sortedr = np.sort(sub_band, axis=-2)
+        valley[k] = np.mean(sortedr[:idx], axis=-2)
+        peak[k] = np.mean(sortedr[-idx:], axis=-2)
+    return peak, valley
+
+
+def spectral_contrast(y, sr, **kw):
+    peak, valley = spectral_contrast_parts(y, sr, **kw)
+    return power_to_db(peak) - power_to_db(valley)
+
+
+def extract_spectral_features(y, sr):
+    """The dict of 04_feature_extraction_experiment/feature_extractor.py:509-518."""
+    c, b, r = spectral_centroid(y, sr)[0], spectral_bandwidth(y, sr)[0], spectral_rolloff(y, sr)[0]
+    con = spectral_contrast(y, sr)
+    return {"spectral_centroid_mean": np.mean(c), "spectral_centroid_std": np.std(c),
+            "spectral_bandwidth_mean": np.mean(b), "spectral_bandwidth_std": np.std(b),
+            "spectral_rolloff_mean": np.mean(r), "spectral_rolloff_std": np.std(r),
+            "spectral_contrast_mean": np.mean(con), "spectral_contrast_std": np.std(con)}
+
+
 def extract_stats(y_raw, sr=22050, frame_length=1024, hop_length=256, n_mfcc=13,
                   pre_emphasis=0.97, window="hamming", n_mels=128,
                   dtype=np.float32, return_frames: bool = False, fmin=0.0, fmax=None, htk=False, lifter=0.0):

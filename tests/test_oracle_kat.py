@@ -228,3 +228,46 @@ def test_zero_crossing_rate_known_answers():
     half = np.concatenate([np.ones(2048, np.float32), -np.ones(2048, np.float32)])
     z = R.zero_crossing_rate(half, 1024, 256)
     assert z.max() == 1 / 1024 and (z > 0).sum() == 3            # 4 frames span the crossing; in one it is slot 0, which never counts
+
+
+# ---- sibling frame features (librosa.feature.spectral_*): known answers -----------------------------------------
+def test_spectral_centroid_of_a_bin_centred_sinusoid_is_its_frequency():
+    sr, n_fft = 22050, 2048
+    k = 100
+    f0 = k * sr / n_fft
+    t = np.arange(sr) / sr
+    y = np.sin(2 * np.pi * f0 * t).astype(np.float32)
+    c = R.spectral_centroid(y, sr)[0]
+    mid = c[4:-4]                                   # frames fully inside the tone
+    assert np.abs(mid - f0).max() < 0.02 * sr / n_fft          # Hann leakage is symmetric about the bin
+    bw = R.spectral_bandwidth(y, sr)[0][4:-4]
+    assert bw.max() < 3 * sr / n_fft                # three bins of main lobe
+
+
+def test_spectral_rolloff_of_white_noise_and_of_silence():
+    sr = 22050
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(4 * sr).astype(np.float32)
+    r = R.spectral_rolloff(y, sr)[0][4:-4]
+    assert abs(np.mean(r) - 0.85 * sr / 2) < 0.02 * sr / 2       # flat spectrum: 85 % of the band
+    z = np.zeros(sr, np.float32)
+    assert (R.spectral_rolloff(z, sr) == 0).all() and (R.spectral_centroid(z, sr) == 0).all()
+
+
+def test_spectral_contrast_bands_and_flat_spectrum():
+    sr = 22050
+    rng = np.random.default_rng(1)
+    y = rng.standard_normal(2 * sr).astype(np.float32)
+    peak, valley = R.spectral_contrast_parts(y, sr)
+    assert peak.shape == valley.shape == (7, 1 + y.size // 512)
+    assert (peak >= valley).all()
+    con = R.spectral_contrast(y, sr)
+    assert 5 < con[6].mean() < 40 and con[6].mean() > con[0].mean()        # 431 noise bins spread wider than 18
+    with pytest.raises(ValueError):
+        R.spectral_contrast_parts(y, 12000)                 # 6400 Hz >= Nyquist
+    # an impulse has a flat magnitude spectrum: peak == valley in the frame that holds it alone
+    imp = np.zeros(8192, np.float32)
+    imp[4096] = 1.0
+    pk, vl = R.spectral_contrast_parts(imp, sr)
+    t = 4096 // 512
+    np.testing.assert_allclose(pk[:, t], vl[:, t], rtol=1e-5)
