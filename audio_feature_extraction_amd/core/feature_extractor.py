@@ -190,8 +190,16 @@ class AudioFeatureExtractor:
         return self._stats_to_dicts(self._run_one(y, 0))[0]
 
     def extract_energy(self, y: np.ndarray) -> Dict[str, Any]:
-        """提取能量特徵 of an already preprocessed signal (feature_extractor.py:153-179)."""
-        return self._stats_to_dicts(self._run_one(y, 0))[1]
+        """提取能量特徵 of an already preprocessed signal (feature_extractor.py:153-179).  Only ``librosa.feature.rms``
+        is involved there, so a clip with fewer than 9 frames -- which fails ``extract_mfcc`` on the width-9 delta --
+        still has its energy statistics."""
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        out = self._plan().extract_batch(y, np.zeros(1, np.int64), np.array([y.size], np.int64), flags=0)
+        st = int(out["status"][0])
+        rms_from_sums = 512 % self.hop_length == 0 and 512 // self.hop_length <= 4      # the kernels' sub-block RMS route
+        if st != _native.CLIP_OK and not (st == _native.CLIP_TOO_SHORT and y.size >= 2 and out["nframes"][0] >= 1 and rms_from_sums):
+            raise _status_error(st, "extract_energy", int(out["nframes"][0]))
+        return self._stats_to_dicts(out["stats"][0])[1]
 
     def extract_features(self, audio_path: str) -> Dict[str, Any]:
         """提取所有特徵 (feature_extractor.py:181-213)."""

@@ -153,12 +153,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     }
   };
 
-  const int total_waves = gridDim.x * WAVES;
-  for (int b = blockIdx.x * WAVES + wave; b < nblocks; b += total_waves) {
-    const BlockDesc bd = blocks[b];
+  // A wave takes a contiguous run of the block list.  Consecutive blocks of one clip then continue the row pipeline
+  // across the block boundary (8 new rows, as inside a block) instead of re-loading 20 rows: no halo re-read between
+  // the blocks of a run, no exposed load latency at a block's start.
+  const int total_waves = gridDim.x * WAVES, wg = blockIdx.x * WAVES + wave;
+  const int b_lo = (int)((int64_t)wg * nblocks / total_waves), b_hi = (int)((int64_t)(wg + 1) * nblocks / total_waves);
+  for (int b = b_lo; b < b_hi; ++b) {
+    BlockDesc bd = blocks[b];
     if (!bd.active) continue;
+    bool first = true;                                    // first block of a run: its 20 rows are loaded; later ones inherit them
+    v2 R[16];
+    for (;;) {                                            // the blocks of one run
     const int Tleft = bd.T - bd.t0;                       // frames left from this block on (>= 1)
     const int npairs = Tleft >= 16 ? 8 : (Tleft + 1) >> 1;
+    bool chain = false;                                   // block b + 1 is this clip's next block and this wave's
+    if (SPEC && npairs == 8 && b + 1 < b_hi) {
+      const BlockDesc* nx = blocks + b + 1;
+      chain = nx->active && nx->clip == bd.clip && nx->t0 == bd.t0 + 16;
+    }
     const int64_t sbase = bd.sample_base;
     const sample_t* const sp = (const sample_t*)samples + sbase;      // staged sample 0 (may lie before the clip: edge path)
     auto interior = [&](int j0, int j1) -> bool {         // every sample of [j0, j1) and its predecessor exists and is kept
@@ -179,8 +191,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
 
     // ---- rows of the first pair: staged samples [0, 1280).  Rows live as pairs R[u] = (row u, row u + 4): exactly the
     // (frame A, frame B) operands of z[u], so the window multiply is one packed instruction per point.
-    v2 R[16];
-    {
+    if (first) {
       float rows[20];
       if (interior(0, N + HOP)) {
         float y[20], yp[20];
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       for (int u = 0; u < 8; ++u) R[u] = R[u + 8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) R[8 + i].x = R[12 + i].y;
-      const bool more = p + 1 < npairs;
+      const bool more = p + 1 < npairs || chain;           // the next pair may be the next block's first
       const int jn = 512 * (p + 1) + 768;                  // staged samples [jn, jn + 512)
       const bool nint = more && interior(jn, jn + 512);
 
@@ -410,6 +421,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       if constexpr (SPEC) { if (lane == 0) blockmax[b] = mx; }
       else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx)); }
     }
+    if (!chain) break;
+    first = false;
+    ++b;
+    bd = blocks[b];
+    }
   }
 }
 
@@ -536,7 +552,7 @@ __global__ __launch_bounds__(256) void k_trim_decide3(const ClipDesc* __restrict
     }
   }
   // ---- RMS rows from the sub-block sums (feature_extractor.py:164, librosa.feature.rms center=True), trimmed frame index
-  if (rms_rows && status == AFX_CLIP_OK) {
+  if (rms_rows && (status == AFX_CLIP_OK || (status == AFX_CLIP_TOO_SHORT && N >= 2))) {      // extract_energy needs no delta
     const float* bs = bsum + cd.tblk_base * per;
     const int64_t s_lo = start / hop, s_hi = (end + hop - 1) / hop;
     const int nsb = kp.n_fft / hop, back = nsb / 2;

@@ -307,7 +307,8 @@ __global__ __launch_bounds__(256) void k_trim_decide(const ClipDesc* __restrict_
   // RMS rows from the sub-block sums (feature_extractor.py:164, librosa.feature.rms center=True): frame t
   // covers kept samples [start + t*hop - n_fft/2, + n_fft); start is a multiple of the sub-block (= hop),
   // `end` is a multiple of it or the clip end, so the frame is a run of whole sub-blocks clipped to the kept span.
-  if (kp.rms_sub > 0 && rms_rows && status == AFX_CLIP_OK) {
+  // (also for a clip too short for the width-9 delta: extract_energy only needs librosa.feature.rms, F:164)
+  if (kp.rms_sub > 0 && rms_rows && (status == AFX_CLIP_OK || (status == AFX_CLIP_TOO_SHORT && N >= 2))) {
     const float* bs = bsum + cd.tblk_base * kp.rms_sub;
     const int64_t s_lo = start / kp.hop, s_hi = (end + kp.hop - 1) / kp.hop;
     const int nsb = kp.n_fft / kp.hop, back = nsb / 2;
@@ -1665,14 +1666,17 @@ __global__ __launch_bounds__(256) void k_stats(const ClipDesc* __restrict__ clip
   if (row > K) return;
   const ClipInfo ci = info[clip];
   float* st = stats + (int64_t)clip * (4 * K + 3);
-  if (ci.status != AFX_CLIP_OK) {
+  const ClipDesc cd = clips[clip];
+  // a clip with fewer than 9 frames fails the MFCC rows (librosa.feature.delta raises) but still has an RMS row:
+  // extract_energy (F:153-179) only calls librosa.feature.rms
+  const bool energy_only = ci.status == AFX_CLIP_TOO_SHORT && cd.len >= 2 && ci.T >= 1 && kp.rms_sub > 0;   // RMS rows from the sub-block sums
+  if (ci.status != AFX_CLIP_OK && !(energy_only && row == K)) {
     if (lane == 0) {
       if (row < K) { st[row] = 0.f; st[K + row] = 0.f; st[2 * K + row] = 0.f; st[3 * K + row] = 0.f; }
       else { st[4 * K] = 0.f; st[4 * K + 1] = 0.f; st[4 * K + 2] = 0.f; }
     }
     return;
   }
-  const ClipDesc cd = clips[clip];
   const int T = ci.T;
   const double invT = 1.0 / (double)T;
   float* fo = frames_out ? frames_out + frame_offsets[clip] : nullptr;

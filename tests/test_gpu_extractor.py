@@ -186,3 +186,20 @@ def test_batch_process_with_several_workers_per_gpu(tmp_path):
         assert list(one) == KEYS
         for k in KEYS[1:]:
             np.testing.assert_allclose(np.asarray(d[k], np.float64), np.asarray(one[k], np.float64), rtol=1e-6, atol=1e-9)
+
+
+def test_extract_energy_of_a_clip_too_short_for_the_delta():
+    """extract_energy only calls librosa.feature.rms (feature_extractor.py:164), so a clip with fewer
+    than 9 frames has energy statistics even though extract_mfcc raises on the width-9 delta."""
+    from oracle import cpu_ref as R
+    ex = AudioFeatureExtractor()
+    for n in (700, 1500, 2047):                      # 3, 6, 8 frames
+        y = make_clip(90, 22050, 0.2)[:n].copy()
+        e = ex.extract_energy(y)
+        ref = R.extract_energy(y, 1024, 256)
+        for k in ("energy_mean", "energy_std", "energy_range"):
+            assert type(e[k]) is float and abs(e[k] - float(ref[k])) <= 1e-5 * max(abs(float(ref[k])), 1e-3), (n, k)
+        with pytest.raises(ValueError):
+            ex.extract_mfcc(y)
+    with pytest.raises(ValueError):
+        ex.extract_energy(np.array([0.3], np.float32))
