@@ -79,7 +79,7 @@ struct afx_plan {
 // the multi-chunk paths be exercised with small batches.
 struct DevEnv {
   int debug_skip = 0, f0_debug = 0;
-  bool stamps = false, f3_debug = false, no_spec = false;
+  bool stamps = false, f3_debug = false, no_spec = false, no_tickets = false;
   int chunk_clips = 32768;
   int64_t f0_chunk_frames = 1280 * 1024;
   const char* f0_dump = nullptr;
@@ -89,6 +89,7 @@ struct DevEnv {
     stamps = getenv("AFX_DEBUG_STAMPS") != nullptr;
     f3_debug = getenv("AFX_F3_DEBUG") != nullptr;
     no_spec = getenv("AFX_NO_SPEC") != nullptr;
+    no_tickets = getenv("AFX_NO_TICKETS") != nullptr;      // A/B: equal static shares in the speculative frame launch
     if (const char* v = getenv("AFX_TEST_CHUNK_CLIPS")) chunk_clips = std::max(1, std::min(32768, atoi(v)));
     if (const char* v = getenv("AFX_TEST_F0_CHUNK_FRAMES")) f0_chunk_frames = std::max<int64_t>(64, atoll(v));
     f0_dump = getenv("AFX_F0_DUMP");
@@ -488,11 +489,12 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
     const int max_items = n * kF3ItemsPerClip;
     HIP_TRY(hipMemsetAsync(pl->n_items.p, 0, 16, s));
     TIMED(AFX_K_FRAMES, launch_frames3_any(s, d_samples, d_info, (const BlockDesc*)pl->blocks_spec.p, pl->nblocks, nullptr, pl->f3, kp,
-                                       (float*)pl->logmel.p, (float*)pl->blockmax.p, (float*)pl->bsum.p, true, pl->n_cu));
+                                       (float*)pl->logmel.p, (float*)pl->blockmax.p, (float*)pl->bsum.p, true,
+                                       dev_env().no_tickets ? nullptr : (int*)pl->n_items.p + 1, pl->n_cu));
     TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide3(s, d_clips, d_info, (const float*)pl->bsum.p, (const float*)pl->blockmax.p,
                                                  (BlockDesc*)pl->items.p, (int*)pl->n_items.p, max_items, (float*)pl->rms.p, n, kp));
     TIMED(AFX_K_TRIM_BLOCKS, launch_frames3_any(s, d_samples, d_info, (const BlockDesc*)pl->items.p, max_items, (const int*)pl->n_items.p,
-                                            pl->f3, kp, (float*)pl->logmel.p, nullptr, nullptr, false, pl->n_cu));
+                                            pl->f3, kp, (float*)pl->logmel.p, nullptr, nullptr, false, nullptr, pl->n_cu));
     TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax, true, true));
   } else {
   TIMED(AFX_K_TRIM_BLOCKS, launch_trim_blocks(s, d_samples, d_clips, d_info, (float*)pl->bsum.p, n, pl->max_tblocks, kp));
@@ -507,7 +509,7 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
     }
     if (f3)
       TIMED(AFX_K_FRAMES, launch_frames3_any(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks, nullptr, pl->f3, kp,
-                                         (float*)pl->logmel.p, nullptr, nullptr, false, pl->n_cu));
+                                         (float*)pl->logmel.p, nullptr, nullptr, false, nullptr, pl->n_cu));
     else
       TIMED(AFX_K_FRAMES, launch_frames(s, d_samples, d_info, (const BlockDesc*)pl->blocks.p, pl->nblocks,
                                         pl->dt, kp, (float*)pl->logmel.p, (float*)pl->rms.p, grid, d_stamps));

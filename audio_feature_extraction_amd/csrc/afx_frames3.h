@@ -49,10 +49,12 @@ size_t frames3_lds_bytes(int waves, const F3Tables& ft);
 bool frames3_eligible(const KParams& kp, const F3Tables& ft);
 int frames3_waves(const F3Tables& ft);
 // spec = true: the speculative first launch over the host-built absolute blocks (emits bsum / blockmax);
-// spec = false: blocks come from a device-built list whose length is *nblocks_dev (nblocks = its capacity)
+// spec = false: blocks come from a device-built list whose length is *nblocks_dev (nblocks = its capacity).
+// work_ctr: a zeroed device int -> the waves take the second half of the list by ticket (runs that shrink towards the
+// end) instead of equal shares; nullptr -> equal contiguous shares
 hipError_t launch_frames3(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                           const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
-                          float* blockmax, float* bsum, bool spec, int n_cu);
+                          float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu);
 // the same for n_fft 2048 / hop 512 (afx_frames3s.hip: one frame per FFT, real-FFT split) and n_fft 512 / hop 128
 // (afx_frames3d.hip: two frame pairs per wave)
 size_t frames3s_lds_bytes(int waves, const F3Tables& ft);
@@ -76,7 +78,7 @@ hipError_t launch_spectral(hipStream_t s, const void* samples, ClipInfo* info, c
 // dispatch on kp.n_fft
 hipError_t launch_frames3_any(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                               const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
-                              float* blockmax, float* bsum, bool spec, int n_cu);
+                              float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu);
 constexpr int kF3ItemsPerClip = 6;         // redo-list capacity per clip (k_trim_decide3)
 hipError_t launch_trim_decide3(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum, const float* blockmax,
                                BlockDesc* items, int* n_items, int max_items, float* rms_rows, int n_clips, const KParams& kp);

@@ -56,6 +56,13 @@ size_t frames3_lds_bytes(int waves, const F3Tables& ft) {
 // maximum per block (blockmax), from which k_trim_decide3 takes the clip maximum over the blocks that survive the
 // cut.  !SPEC (second launch): the few blocks around a cut (device-built list, count in *nblocks_dev), frames
 // recomputed with the trimmed span masked, maxima merged by atomicMax.  The samples are thus read once per batch.
+#ifdef AFX_F3_DEBUG
+// diagnostic build only: per wave of the speculative launch, wall clock (100 MHz) at entry, after the table set-up and at
+// the end, and the hardware id (HW_ID | XCC_ID << 32)
+__device__ unsigned long long g_f3_stamps[4 * 8192];
+__device__ unsigned long long g_f3_blk[65536];       // wall clock at the end of block b
+#endif
+
 template <int FMT, int WAVES, int NB0, int NB1, bool SPEC>
 __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__ samples,
                                                         ClipInfo* __restrict__ info,
@@ -64,11 +71,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
                                                         F3Tables ft, KParams kp,
                                                         float* __restrict__ logmel,
                                                         float* __restrict__ blockmax,
-                                                        float* __restrict__ bsum) {
+                                                        float* __restrict__ bsum,
+                                                        int* __restrict__ work_ctr) {
   constexpr int N = 1024, HOP = 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef AFX_F3_DEBUG
+  const unsigned long long stamp0 = wall_clock64();
+#endif
   float* const tabs = smem + WAVES * kF3ExFloats;
   v2* const T2 = reinterpret_cast<v2*>(tabs);                 // [r][16]: W_128^(c r)
   v2* const T3a = reinterpret_cast<v2*>(tabs + 256);          // [r-1][lane]: W_1024^(ja r)
@@ -157,7 +168,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
   // across the block boundary (8 new rows, as inside a block) instead of re-loading 20 rows: no halo re-read between
   // the blocks of a run, no exposed load latency at a block's start.
   const int total_waves = gridDim.x * WAVES, wg = blockIdx.x * WAVES + wave;
-  const int b_lo = (int)((int64_t)wg * nblocks / total_waves), b_hi = (int)((int64_t)(wg + 1) * nblocks / total_waves);
+#ifdef AFX_F3_DEBUG
+  const unsigned long long stamp1 = wall_clock64();
+#endif
+  // Which runs: with a work counter (the speculative launch), about half of the list is dealt out up front, C0 blocks per
+  // wave, and the rest is taken by ticket in runs that shrink (C0 / 2, C0 / 3, then single blocks).  The four waves of a
+  // SIMD do not advance at one speed (the issue arbiter favours the oldest: measured 615 .. 900 us for equal static
+  // shares), so equal shares leave the SIMDs under-occupied for the last third of the launch; tickets let the waves
+  // that run ahead take more.  Without a counter (the short list launch): equal contiguous shares.
+  int b_lo, b_hi, dyn0 = 0, cA = 1, cB = 1;
+  if (work_ctr) {
+    const int C0 = nblocks / (2 * total_waves);
+    b_lo = wg * C0; b_hi = b_lo + C0; dyn0 = total_waves * C0;
+    cA = C0 / 2 > 1 ? C0 / 2 : 1; cB = C0 / 3 > 1 ? C0 / 3 : 1;
+  } else {
+    b_lo = (int)((int64_t)wg * nblocks / total_waves); b_hi = (int)((int64_t)(wg + 1) * nblocks / total_waves);
+  }
+  for (;;) {                                              // the runs of this wave
   for (int b = b_lo; b < b_hi; ++b) {
     BlockDesc bd = blocks[b];
     if (!bd.active) continue;
@@ -421,13 +448,43 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       if constexpr (SPEC) { if (lane == 0) blockmax[b] = mx; }
       else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx)); }
     }
+#ifdef AFX_F3_DEBUG
+    if (SPEC && lane == 0 && b < 65536) g_f3_blk[b] = wall_clock64();
+#endif
     if (!chain) break;
     first = false;
     ++b;
     bd = blocks[b];
     }
   }
+  if (!work_ctr) break;
+  int t = 0;
+  if (lane == 0) t = atomicAdd(work_ctr, 1);
+  t = __builtin_amdgcn_readfirstlane(t);
+  int c = 1;
+  if (t < total_waves) { b_lo = dyn0 + cA * t; c = cA; }
+  else if (t < 2 * total_waves) { b_lo = dyn0 + cA * total_waves + cB * (t - total_waves); c = cB; }
+  else b_lo = dyn0 + (cA + cB) * total_waves + (t - 2 * total_waves);
+  if (b_lo >= nblocks) break;
+  b_hi = b_lo + c < nblocks ? b_lo + c : nblocks;
+  }
+#ifdef AFX_F3_DEBUG
+  if (SPEC && lane == 0 && wg < 8192) {
+    g_f3_stamps[4 * wg] = stamp0; g_f3_stamps[4 * wg + 1] = stamp1; g_f3_stamps[4 * wg + 2] = wall_clock64();
+    g_f3_stamps[4 * wg + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                              ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
+#endif
 }
+
+#ifdef AFX_F3_DEBUG
+extern "C" __attribute__((visibility("default"))) int afx_debug_f3_stamps(unsigned long long* out, int n_waves) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f3_stamps), sizeof(unsigned long long) * 4 * (size_t)n_waves);
+}
+extern "C" __attribute__((visibility("default"))) int afx_debug_f3_blocks(unsigned long long* out, int n_blocks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f3_blk), sizeof(unsigned long long) * (size_t)n_blocks);
+}
+#endif
 
 
 // ---------------------------------------------------------------------------
@@ -581,10 +638,10 @@ bool frames3_eligible(const KParams& kp, const F3Tables& ft) {
 
 hipError_t launch_frames3_any(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                               const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
-                              float* blockmax, float* bsum, bool spec, int n_cu) {
+                              float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu) {
   if (kp.n_fft == 2048) return launch_frames3s(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, spec, n_cu);
   if (kp.n_fft == 512) return launch_frames3d(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, spec, n_cu);
-  return launch_frames3(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, spec, n_cu);
+  return launch_frames3(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, spec, work_ctr, n_cu);
 }
 
 int frames3_waves(const F3Tables& ft) {
@@ -596,7 +653,7 @@ int frames3_waves(const F3Tables& ft) {
 template <int FMT, int WAVES, int NB0, int NB1, bool SPEC>
 static hipError_t launch_frames3_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
                                    int nblocks, const int* nblocks_dev, const F3Tables& ft, const KParams& kp,
-                                   float* logmel, float* blockmax, float* bsum, int n_cu) {
+                                   float* logmel, float* blockmax, float* bsum, int* work_ctr, int n_cu) {
   static bool attr_set[64] = {};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -609,31 +666,31 @@ static hipError_t launch_frames3_t(hipStream_t s, const void* samples, ClipInfo*
   }
   const int grid = std::max(1, std::min(n_cu, (nblocks + WAVES - 1) / WAVES));
   hipLaunchKernelGGL((k_frames3<FMT, WAVES, NB0, NB1, SPEC>), dim3(grid), dim3(WAVES * 64), frames3_lds_bytes(WAVES, ft), s,
-                     samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum);
+                     samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr);
   return hipGetLastError();
 }
 
 template <int FMT, int WAVES, bool SPEC>
 static hipError_t launch_frames3_w(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
                                    int nblocks, const int* nblocks_dev, const F3Tables& ft, const KParams& kp,
-                                   float* logmel, float* blockmax, float* bsum, int n_cu) {
+                                   float* logmel, float* blockmax, float* bsum, int* work_ctr, int n_cu) {
   // straight-line mel schedules compiled in: two rounds of width 1
   const bool two = ft.mel_rounds == 2 && ((ft.mel_rp[0] >> 4) & 15) == 1 && ((ft.mel_rp[1] >> 4) & 15) == 1 &&
                    !getenv("AFX_F3_GENERIC_MEL");
   const int nb0 = ft.mel_rp[0] & 15, nb1 = ft.mel_rp[1] & 15;
   if (two && nb0 == 2 && nb1 == 7)
-    return launch_frames3_t<FMT, WAVES, 2, 7, SPEC>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu);
-  return launch_frames3_t<FMT, WAVES, 0, 0, SPEC>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu);
+    return launch_frames3_t<FMT, WAVES, 2, 7, SPEC>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu);
+  return launch_frames3_t<FMT, WAVES, 0, 0, SPEC>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu);
 }
 
 // spec: the speculative first launch (host-built blocks; emits bsum / blockmax); otherwise the list launch
 hipError_t launch_frames3(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                           const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
-                          float* blockmax, float* bsum, bool spec, int n_cu) {
+                          float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu) {
   const int waves = frames3_waves(ft);
 #define AFX_F3_GO(FMT, W)                                                                                                   \
-  (spec ? launch_frames3_w<FMT, W, true>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu) \
-        : launch_frames3_w<FMT, W, false>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu))
+  (spec ? launch_frames3_w<FMT, W, true>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu) \
+        : launch_frames3_w<FMT, W, false>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu))
   if (kp.fmt == AFX_FMT_S16) return waves == 16 ? AFX_F3_GO(AFX_FMT_S16, 16) : AFX_F3_GO(AFX_FMT_S16, 12);
   return waves == 16 ? AFX_F3_GO(AFX_FMT_F32, 16) : AFX_F3_GO(AFX_FMT_F32, 12);
 #undef AFX_F3_GO
