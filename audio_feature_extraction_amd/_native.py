@@ -27,7 +27,7 @@ SYMBOLS = (
     "afx_version", "afx_device_count", "afx_last_error", "afx_init", "afx_destroy",
     "afx_malloc", "afx_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
     "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables", "afx_build_mel_schedule",
-    "afx_extract_batch", "afx_f0_batch", "afx_zcr_batch", "afx_spectral_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings", "afx_plan_get_intervals",
+    "afx_extract_batch", "afx_extract_submit", "afx_extract_collect", "afx_f0_batch", "afx_zcr_batch", "afx_spectral_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings", "afx_plan_get_intervals",
 )
 
 
@@ -80,6 +80,8 @@ def lib() -> C.CDLL:
         L.afx_build_tables.argtypes = [C.POINTER(Params), vp, vp, vp]
         L.afx_build_mel_schedule.argtypes = [C.POINTER(Params), vp, vp, vp]
         L.afx_extract_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+        L.afx_extract_submit.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+        L.afx_extract_collect.argtypes = [vp]
         L.afx_f0_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, C.c_double, C.c_double, vp, vp, vp, vp]
         L.afx_zcr_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp]
         L.afx_spectral_batch.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp]
@@ -229,8 +231,9 @@ class Plan:
         """HBM allocation on this plan's device (the seam parallel.process_files uploads a window through)."""
         return DeviceBuffer(self.ctx, nbytes)
 
-    def set_timing(self, on: bool):
-        _check(lib().afx_plan_set_timing(self.handle, 1 if on else 0), "afx_plan_set_timing")
+    def set_timing(self, on, frames_only: bool = False):
+        """HIP events around every kernel of a batch (or, frames_only, around the frame kernel alone)."""
+        _check(lib().afx_plan_set_timing(self.handle, (2 if frames_only else 1) if on else 0), "afx_plan_set_timing")
 
     def timings(self, reset: bool = True):
         ms = np.zeros(len(K_NAMES), np.float32)
@@ -247,10 +250,7 @@ class Plan:
         n = min(int(cnt.value), cap)
         return np.stack([st[:n], en[:n]], axis=1)
 
-    def extract_batch(self, samples, offsets, lengths, flags=FLAG_PREEMPH | FLAG_TRIM,
-                      fmt=FMT_F32, want_frames: bool = False, out=None):
-        """samples: numpy array (host) or DeviceBuffer/int device pointer.  Returns a dict with
-        stats [n, 4K+3], status [n], trim [n, 2], nframes [n] (and frames list when asked)."""
+    def _extract_args(self, samples, offsets, lengths, fmt, want_frames, out):
         offsets = np.ascontiguousarray(offsets, np.int64)
         lengths = np.ascontiguousarray(lengths, np.int64)
         n = int(offsets.shape[0])
@@ -282,20 +282,51 @@ class Plan:
                 foffs[1:] = np.cumsum(rows * tmax)[:-1]
             frames = np.zeros(int((rows * tmax).sum()) if n else 0, np.float32)
             fptr, foffs_ptr = frames.ctypes.data, foffs.ctypes.data
-        rc = lib().afx_extract_batch(
-            self.handle, sptr, int(fmt), kind, offsets.ctypes.data, lengths.ctypes.data, n, int(flags),
-            out["stats"].ctypes.data, out["status"].ctypes.data, out["trim"].ctypes.data,
-            out["nframes"].ctypes.data, fptr, foffs_ptr)
-        _check(rc, "afx_extract_batch")
+        args = (self.handle, sptr, int(fmt), kind, offsets.ctypes.data, lengths.ctypes.data, n, int(self._flags),
+                out["stats"].ctypes.data, out["status"].ctypes.data, out["trim"].ctypes.data,
+                out["nframes"].ctypes.data, fptr, foffs_ptr)
+        keep = (samples, offsets, lengths, frames, foffs)       # alive until the call (or the collect) is over
+        return args, out, keep
+
+    def _frames_out(self, out, keep, want_frames):
         if want_frames:
+            _, _, lengths, frames, foffs = keep
+            K, hop = self.params.n_mfcc, self.params.hop
             res = []
-            for i in range(n):
+            for i in range(int(lengths.shape[0])):
                 tm, T = int(1 + lengths[i] // hop), int(out["nframes"][i])
                 blk = frames[foffs[i]: foffs[i] + (3 * K + 1) * tm].reshape(3 * K + 1, tm)[:, :T]
                 res.append({"mfcc": blk[:K].copy(), "mfcc_delta": blk[K:2 * K].copy(),
                             "mfcc_delta2": blk[2 * K:3 * K].copy(), "rms": blk[3 * K:].copy()})
             out["frames"] = res
         return out
+
+    def extract_batch(self, samples, offsets, lengths, flags=FLAG_PREEMPH | FLAG_TRIM,
+                      fmt=FMT_F32, want_frames: bool = False, out=None):
+        """samples: numpy array (host) or DeviceBuffer/int device pointer.  Returns a dict with
+        stats [n, 4K+3], status [n], trim [n, 2], nframes [n] (and frames list when asked)."""
+        self._flags = flags
+        args, out, keep = self._extract_args(samples, offsets, lengths, fmt, want_frames, out)
+        _check(lib().afx_extract_batch(*args), "afx_extract_batch")
+        return self._frames_out(out, keep, want_frames)
+
+    def extract_submit(self, samples, offsets, lengths, flags=FLAG_PREEMPH | FLAG_TRIM,
+                       fmt=FMT_F32, want_frames: bool = False, out=None):
+        """First half of extract_batch: queues the batch on the context's stream and returns.  extract_collect() waits
+        for it and returns the result dict.  Two plans of one context used alternately keep the device busy while
+        the host takes one batch's results and submits the next."""
+        self._flags = flags
+        args, out, keep = self._extract_args(samples, offsets, lengths, fmt, want_frames, out)
+        _check(lib().afx_extract_submit(*args), "afx_extract_submit")
+        self._pending = (out, keep, want_frames)
+
+    def extract_collect(self):
+        if getattr(self, "_pending", None) is None:
+            raise AfxError("extract_collect: nothing submitted")
+        out, keep, want_frames = self._pending
+        self._pending = None
+        _check(lib().afx_extract_collect(self.handle), "afx_extract_collect")
+        return self._frames_out(out, keep, want_frames)
 
     def f0_batch(self, samples, offsets, lengths, fmin: float, fmax: float,
                  flags=FLAG_PREEMPH | FLAG_TRIM, fmt=FMT_F32, want_frames: bool = False):

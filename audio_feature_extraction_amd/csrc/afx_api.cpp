@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -63,9 +64,23 @@ struct afx_plan {
   int64_t total_tpad = 0, total_tblk = 0;
   // pinned staging for the small per-call results (a device-to-pageable copy is staged and synchronous)
   void* h_pin = nullptr;
+  void* h_pin_dev = nullptr;       // the same block as the device addresses it
   size_t h_pin_cap = 0;
+  int info_clean_n = 0;            // leading clip records (and the counters) known to be zero on the stream
+  // a submitted, not yet collected chunk (afx_extract_submit / afx_extract_collect; afx_extract_batch = both, per chunk)
+  struct Pending {
+    bool active = false;
+    int n = 0;
+    size_t stats_bytes = 0;
+    float* out_stats = nullptr; int32_t* out_status = nullptr; int64_t* out_trim = nullptr; int32_t* out_nframes = nullptr;
+  } pend;
+  hipEvent_t done = nullptr;       // recorded behind the chunk's last copy: collect waits for this chunk, not for the stream
+  volatile unsigned* flag = nullptr;   // host word the device stores the chunk's sequence number to (behind the same copy)
+  unsigned* flag_dev = nullptr;
+  unsigned seq = 0;
   // timing
   bool timing = false;
+  bool timing_frames_only = false;   // afx_plan_set_timing(plan, 2): events around the frame kernel only
   hipEvent_t ev[AFX_K_COUNT][2] = {};
   bool ev_ready = false;
   double ms_sum[AFX_K_COUNT] = {};
@@ -268,6 +283,8 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
     pl->f3.w1024 = p->n_fft == 2048 ? pl->dt.tw : pl->dt.post;
     pl->f3.w2048 = pl->dt.post;
     pl->f3.mel_rounds = t.f3mel.rounds; pl->f3.mel_wfloats = (int32_t)t.f3mel.w.size();
+    pl->f3.mel_all_own = 1;                        // every lane of every round is the owner of a filter (width-1 rounds, all lanes used)
+    for (size_t i = 0; i < t.f3mel.meta.size(); ++i) if (!(t.f3mel.meta[i] & (1 << 20))) pl->f3.mel_all_own = 0;
     for (int r = 0; r < kF3MaxRounds; ++r)
       pl->f3.mel_rp[r] = (uint32_t)t.f3mel.nb[r] | ((uint32_t)t.f3mel.width[r] << 4) | ((uint32_t)t.f3mel.woff[r] << 8);
   }
@@ -285,6 +302,7 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
 extern "C" void afx_plan_destroy(afx_plan* pl) {
   if (!pl) return;
   (void)hipSetDevice(pl->device);
+  if (pl->pend.active && pl->ctx) (void)hipStreamSynchronize(pl->ctx->stream);   // a submitted batch still writes the plan's memory
   for (void* d : pl->table_allocs) (void)hipFree(d);
   for (void* q : pl->f0_allocs) (void)hipFree(q);
   release(pl->f0_in); release(pl->f0_ysig); release(pl->f0_energy); release(pl->f0_cnt); release(pl->f0_vp);
@@ -295,6 +313,8 @@ extern "C" void afx_plan_destroy(afx_plan* pl) {
   release(pl->frame_offs); release(pl->stamps);
   release(pl->blocks_spec); release(pl->blockmax); release(pl->items); release(pl->n_items);
   if (pl->h_pin) (void)hipHostFree(pl->h_pin);
+  if (pl->done) (void)hipEventDestroy(pl->done);
+  if (pl->flag) (void)hipHostFree((void*)pl->flag);
   if (pl->ev_ready)
     for (int k = 0; k < AFX_K_COUNT; ++k) { (void)hipEventDestroy(pl->ev[k][0]); (void)hipEventDestroy(pl->ev[k][1]); }
   delete pl;
@@ -330,6 +350,7 @@ extern "C" int afx_plan_set_timing(afx_plan* pl, int enable) {
     pl->ev_ready = true;
   }
   pl->timing = enable != 0;
+  pl->timing_frames_only = enable == 2;
   return AFX_OK;
 }
 
@@ -422,16 +443,21 @@ static int prepare_descriptors(afx_plan* pl, const int64_t* offsets, const int64
 
 #define TIMED(slot, call)                                                      \
   do {                                                                         \
-    if (pl->timing) HIP_TRY(hipEventRecord(pl->ev[slot][0], s));               \
+    const bool timed_ = pl->timing && (!pl->timing_frames_only || (slot) == AFX_K_FRAMES);   \
+    if (timed_) HIP_TRY(hipEventRecord(pl->ev[slot][0], s));                   \
     HIP_TRY(call);                                                             \
-    if (pl->timing) { HIP_TRY(hipEventRecord(pl->ev[slot][1], s)); pl->launches[slot]++; } \
+    if (timed_) { HIP_TRY(hipEventRecord(pl->ev[slot][1], s)); pl->launches[slot]++; } \
   } while (0)
 
-static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kind,
+// Everything a chunk needs on the stream, up to the copies of its results into pinned staging; chunk_finish waits and
+// hands the results out.  by_event: wait for the chunk's own event (other plans may have queued work behind it on the
+// same stream) instead of the whole stream.
+static int chunk_enqueue(afx_plan* pl, const void* samples, int fmt, int mem_kind,
                          const int64_t* offsets, const int64_t* lengths, int n, int flags,
                          float* out_stats, int32_t* out_status, int64_t* out_trim, int32_t* out_nframes,
-                         float* out_frames, const int64_t* frame_offsets) {
+                         float* out_frames, const int64_t* frame_offsets, bool by_event) {
   hipStream_t s = pl->ctx->stream;
+  if (pl->pend.active) { set_error("the plan has a submitted batch that has not been collected (afx_extract_collect)"); return AFX_ERR_INVALID; }
   const int K = pl->p.n_mfcc, M = pl->p.n_mels;
   const int nstat = 4 * K + 3;
   int rc;
@@ -446,7 +472,11 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
     if (hi > 0) HIP_TRY(hipMemcpyAsync(pl->samples.p, samples, (size_t)hi * esz, hipMemcpyHostToDevice, s));
     d_samples = pl->samples.p;
   }
-  if ((rc = ensure(pl->info, n * sizeof(ClipInfo))) != AFX_OK) return rc;
+  {
+    const size_t before = pl->info.cap;
+    if ((rc = ensure(pl->info, n * sizeof(ClipInfo))) != AFX_OK) return rc;
+    if (pl->info.cap != before) pl->info_clean_n = 0;          // a new block: contents unknown
+  }
   if ((rc = ensure(pl->bsum, std::max<int64_t>(pl->total_tblk, 1) * 4 * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->logmel, (size_t)pl->total_tpad * M * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->rms, (size_t)pl->total_tpad * sizeof(float))) != AFX_OK) return rc;
@@ -480,14 +510,23 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
   const ClipDesc* d_clips = (const ClipDesc*)pl->clips.p;
   ClipInfo* d_info = (ClipInfo*)pl->info.p;
 
-  HIP_TRY(hipMemsetAsync(d_info, 0, n * sizeof(ClipInfo), s));
+  // the clip records and the list / ticket counters start a batch cleared: k_finish of the previous batch left them so
+  {
+    const size_t before = pl->n_items.cap;
+    if ((rc = ensure(pl->n_items, 16)) != AFX_OK) return rc;
+    if (pl->n_items.cap != before) pl->info_clean_n = 0;
+  }
+  if (pl->info_clean_n < n) {
+    HIP_TRY(hipMemsetAsync(d_info, 0, n * sizeof(ClipInfo), s));
+    HIP_TRY(hipMemsetAsync(pl->n_items.p, 0, 16, s));
+  }
+  pl->info_clean_n = 0;
   const bool want_stamps = dev_env().stamps;     // diagnostic build of k_frames
   const bool f3 = pl->use_f3 && !want_stamps && (!(kp.flags & 0x7f00) || dev_env().f3_debug);
   const bool no_spec = dev_env().no_spec;       // A/B: the two-pass pipeline with k_frames3
   if (f3 && !no_spec && pl->nblocks > 0) {
     // the samples are read once: frames before the trim decision (which the same pass feeds), then the few frames a cut touches
     const int max_items = n * kF3ItemsPerClip;
-    HIP_TRY(hipMemsetAsync(pl->n_items.p, 0, 16, s));
     TIMED(AFX_K_FRAMES, launch_frames3_any(s, d_samples, d_info, (const BlockDesc*)pl->blocks_spec.p, pl->nblocks, nullptr, pl->f3, kp,
                                        (float*)pl->logmel.p, (float*)pl->blockmax.p, (float*)pl->bsum.p, true,
                                        dev_env().no_tickets ? nullptr : (int*)pl->n_items.p + 1, pl->n_cu));
@@ -539,24 +578,68 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
     TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax, f3));
   }
   }
-  TIMED(AFX_K_STATS, launch_stats(s, d_clips, d_info, kp, (const float*)pl->mfcc.p, (const float*)pl->rms.p,
-                                  (float*)pl->stats.p, d_frames, (const int64_t*)pl->frame_offs.p, n));
-
+  // The batch's small results (statistics, clip records) are written by k_stats straight into pinned host memory the
+  // device can address: no copy commands behind the last kernel (each cost ~15 us of stream time).
   const size_t stats_bytes = (size_t)n * nstat * sizeof(float), info_bytes = (size_t)n * sizeof(ClipInfo);
   if (pl->h_pin_cap < stats_bytes + info_bytes) {
+    HIP_TRY(hipStreamSynchronize(s));                                       // nothing in flight may still write the old block
     if (pl->h_pin) (void)hipHostFree(pl->h_pin);
-    pl->h_pin = nullptr; pl->h_pin_cap = 0;
+    pl->h_pin = nullptr; pl->h_pin_cap = 0; pl->h_pin_dev = nullptr;
     const size_t want = (stats_bytes + info_bytes) * 5 / 4 + 256;          // slack covers the 16-byte round-up
-    HIP_TRY(hipHostMalloc(&pl->h_pin, want, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&pl->h_pin, want, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(&pl->h_pin_dev, pl->h_pin, 0));
     pl->h_pin_cap = want;
   }
-  float* h_stats = (float*)pl->h_pin;
-  const ClipInfo* h_info = (const ClipInfo*)((char*)pl->h_pin + ((stats_bytes + 15) & ~(size_t)15));
-  HIP_TRY(hipMemcpyAsync(h_stats, pl->stats.p, stats_bytes, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync((void*)h_info, d_info, info_bytes, hipMemcpyDeviceToHost, s));
+  const size_t info_at = (stats_bytes + 15) & ~(size_t)15;
+  TIMED(AFX_K_STATS, launch_stats(s, d_clips, d_info, kp, (const float*)pl->mfcc.p, (const float*)pl->rms.p,
+                                  (float*)pl->h_pin_dev, d_frames, (const int64_t*)pl->frame_offs.p, n,
+                                  (ClipInfo*)((char*)pl->h_pin_dev + info_at)));
   if (out_frames && f_hi > f_lo)
     HIP_TRY(hipMemcpyAsync(out_frames + f_lo, d_frames, (size_t)(f_hi - f_lo) * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  if (by_event) {
+    if (!pl->done) HIP_TRY(hipEventCreateWithFlags(&pl->done, hipEventDisableTiming));
+    if (!pl->flag) {
+      void* h = nullptr;
+      HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped));
+      std::memset(h, 0, 64);
+      pl->flag = (volatile unsigned*)h;
+      HIP_TRY(hipHostGetDevicePointer((void**)&pl->flag_dev, h, 0));
+    }
+  }
+  HIP_TRY(launch_finish(s, d_info, n, (int*)pl->n_items.p, by_event ? pl->flag_dev : nullptr, by_event ? ++pl->seq : 0u));
+  pl->info_clean_n = n;
+  if (by_event) HIP_TRY(hipEventRecord(pl->done, s));
+  pl->pend.active = true; pl->pend.n = n; pl->pend.stats_bytes = stats_bytes;
+  pl->pend.out_stats = out_stats; pl->pend.out_status = out_status; pl->pend.out_trim = out_trim; pl->pend.out_nframes = out_nframes;
+  return AFX_OK;
+}
+
+static int chunk_finish(afx_plan* pl, bool by_event) {
+  if (!pl->pend.active) { set_error("afx_extract_collect: nothing submitted"); return AFX_ERR_INVALID; }
+  hipStream_t s = pl->ctx->stream;
+  pl->pend.active = false;          // whatever happens below, the chunk is over
+  if (by_event) {
+    // spin on the flag; every so often ask the runtime, so that a failed launch ends the wait with its error
+    for (unsigned it = 1; *pl->flag != pl->seq; ++it) {
+      if ((it & 0xfff) == 0) {
+        const hipError_t q = hipEventQuery(pl->done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { set_error(std::string("afx_extract_collect: ") + hipGetErrorString(q)); return AFX_ERR_HIP; }
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else {
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  const int n = pl->pend.n;
+  const size_t stats_bytes = pl->pend.stats_bytes;
+  float* out_stats = pl->pend.out_stats; int32_t* out_status = pl->pend.out_status;
+  int64_t* out_trim = pl->pend.out_trim; int32_t* out_nframes = pl->pend.out_nframes;
+  const float* h_stats = (const float*)pl->h_pin;
+  const ClipInfo* h_info = (const ClipInfo*)((char*)pl->h_pin + ((stats_bytes + 15) & ~(size_t)15));
   if (pl->timing) {
     for (int k = 0; k < AFX_K_COUNT; ++k) {
       if (pl->nblocks == 0 && (k == AFX_K_FRAMES || k == AFX_K_DCT)) continue;
@@ -580,6 +663,49 @@ static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kin
     if (out_nframes) out_nframes[i] = ci.T;
   }
   return AFX_OK;
+}
+
+static int extract_chunk(afx_plan* pl, const void* samples, int fmt, int mem_kind,
+                         const int64_t* offsets, const int64_t* lengths, int n, int flags,
+                         float* out_stats, int32_t* out_status, int64_t* out_trim, int32_t* out_nframes,
+                         float* out_frames, const int64_t* frame_offsets) {
+  int rc = chunk_enqueue(pl, samples, fmt, mem_kind, offsets, lengths, n, flags, out_stats, out_status, out_trim, out_nframes,
+                         out_frames, frame_offsets, false);
+  if (rc != AFX_OK) return rc;
+  return chunk_finish(pl, false);
+}
+
+static int check_extract_args(const char* who, afx_plan* pl, const void* samples, int sample_fmt, int mem_kind,
+                              const int64_t* offsets, const int64_t* lengths, int n_clips, float* out_stats, int32_t* out_status) {
+  if (!pl || !offsets || !lengths || !out_stats || !out_status || n_clips < 0 || (!samples && n_clips > 0)) {
+    set_error(std::string(who) + ": null/invalid argument");
+    return AFX_ERR_INVALID;
+  }
+  if (sample_fmt != AFX_FMT_F32 && sample_fmt != AFX_FMT_S16) { set_error("unknown sample format"); return AFX_ERR_INVALID; }
+  if (mem_kind != AFX_MEM_HOST && mem_kind != AFX_MEM_DEVICE) { set_error("unknown mem_kind"); return AFX_ERR_INVALID; }
+  return AFX_OK;
+}
+
+extern "C" int afx_extract_submit(afx_plan* pl, const void* samples, int sample_fmt, int mem_kind,
+                                  const int64_t* offsets, const int64_t* lengths, int n_clips, int flags,
+                                  float* out_stats, int32_t* out_status, int64_t* out_trim,
+                                  int32_t* out_nframes, float* out_frames, const int64_t* frame_offsets) {
+  int rc = check_extract_args("afx_extract_submit", pl, samples, sample_fmt, mem_kind, offsets, lengths, n_clips, out_stats, out_status);
+  if (rc != AFX_OK) return rc;
+  if (n_clips == 0) { set_error("afx_extract_submit: empty batch"); return AFX_ERR_INVALID; }
+  if (n_clips > dev_env().chunk_clips) { set_error("afx_extract_submit: more clips than one chunk holds; use afx_extract_batch"); return AFX_ERR_UNSUPPORTED; }
+  if (pl->pend.active) { set_error("afx_extract_submit: the plan's previous batch has not been collected"); return AFX_ERR_INVALID; }
+  (void)hipGetLastError();
+  HIP_TRY(hipSetDevice(pl->device));
+  rc = chunk_enqueue(pl, samples, sample_fmt, mem_kind, offsets, lengths, n_clips, flags, out_stats, out_status, out_trim,
+                     out_nframes, out_frames, frame_offsets, true);
+  return rc;
+}
+
+extern "C" int afx_extract_collect(afx_plan* pl) {
+  if (!pl) { set_error("afx_extract_collect: null plan"); return AFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(pl->device));
+  return chunk_finish(pl, true);
 }
 
 extern "C" int afx_extract_batch(afx_plan* pl, const void* samples, int sample_fmt, int mem_kind,
@@ -711,6 +837,7 @@ static int f0_chunk(afx_plan* pl, const void* d_samples, int fmt, const int64_t*
   const ClipDesc* d_clips = (const ClipDesc*)pl->clips.p;
   ClipInfo* d_info = (ClipInfo*)pl->info.p;
   HIP_TRY(hipMemsetAsync(d_info, 0, n * sizeof(ClipInfo), s));
+  pl->info_clean_n = 0;      // this path leaves the clip records used
   HIP_TRY(launch_trim_blocks(s, d_samples, d_clips, d_info, (float*)pl->bsum.p, n, pl->max_tblocks, kp));
   HIP_TRY(launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, nullptr, n, kp));
   HIP_TRY(launch_f0_prep(s, d_samples, d_clips, d_info, (float*)pl->f0_ysig.p, n, max_len, kp));
@@ -759,6 +886,7 @@ extern "C" int afx_f0_batch(afx_plan* pl, const void* samples, int sample_fmt, i
   if (n_clips == 0) return AFX_OK;
   (void)hipGetLastError();
   HIP_TRY(hipSetDevice(pl->device));
+  if (pl->pend.active) { set_error("afx_f0_batch: the plan has a submitted batch that has not been collected"); return AFX_ERR_INVALID; }
   int rc;
   if ((rc = f0_setup(pl, fmin, fmax)) != AFX_OK) return rc;
   const void* d_samples = samples;
@@ -804,6 +932,7 @@ extern "C" int afx_zcr_batch(afx_plan* pl, const void* samples, int sample_fmt, 
   if (n_clips > 32768) { set_error("afx_zcr_batch: at most 32768 clips per call"); return AFX_ERR_INVALID; }
   (void)hipGetLastError();
   HIP_TRY(hipSetDevice(pl->device));
+  if (pl->pend.active) { set_error("afx_zcr_batch: the plan has a submitted batch that has not been collected"); return AFX_ERR_INVALID; }
   hipStream_t s = pl->ctx->stream;
   const int n = n_clips;
   int rc;
@@ -831,6 +960,7 @@ extern "C" int afx_zcr_batch(afx_plan* pl, const void* samples, int sample_fmt, 
   const ClipDesc* d_clips = (const ClipDesc*)pl->clips.p;
   ClipInfo* d_info = (ClipInfo*)pl->info.p;
   HIP_TRY(hipMemsetAsync(d_info, 0, n * sizeof(ClipInfo), s));
+  pl->info_clean_n = 0;      // this path leaves the clip records used
   HIP_TRY(launch_trim_blocks(s, d_samples, d_clips, d_info, (float*)pl->bsum.p, n, pl->max_tblocks, kp));
   HIP_TRY(launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, nullptr, n, kp));
   HIP_TRY(launch_f0_prep(s, d_samples, d_clips, d_info, (float*)pl->f0_ysig.p, n, max_len, kp));
@@ -885,6 +1015,7 @@ extern "C" int afx_spectral_batch(afx_plan* pl, const void* samples, int sample_
   }
   (void)hipGetLastError();
   HIP_TRY(hipSetDevice(pl->device));
+  if (pl->pend.active) { set_error("afx_spectral_batch: the plan has a submitted batch that has not been collected"); return AFX_ERR_INVALID; }
   hipStream_t s = pl->ctx->stream;
   const int n = n_clips;
   int rc;
@@ -912,6 +1043,7 @@ extern "C" int afx_spectral_batch(afx_plan* pl, const void* samples, int sample_
   HIP_TRY(hipMemcpyAsync(pl->frame_offs.p, rebased.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(pl->frames.p, 0, (size_t)(d_hi - d_lo) * sizeof(float), s));
   HIP_TRY(hipMemsetAsync(pl->info.p, 0, n * sizeof(ClipInfo), s));
+  pl->info_clean_n = 0;      // this path leaves the clip records used
   KParams kp = pl->kp;
   kp.flags = flags; kp.fmt = sample_fmt;
   if (pl->nblocks > 0)
@@ -931,6 +1063,7 @@ extern "C" int afx_preprocess(afx_plan* pl, const float* y, int64_t n, float* ou
   }
   (void)hipGetLastError();
   HIP_TRY(hipSetDevice(pl->device));
+  if (pl->pend.active) { set_error("afx_preprocess: the plan has a submitted batch that has not been collected"); return AFX_ERR_INVALID; }
   hipStream_t s = pl->ctx->stream;
   const int64_t off = 0;
   int rc;
@@ -944,6 +1077,7 @@ extern "C" int afx_preprocess(afx_plan* pl, const float* y, int64_t n, float* ou
   kp.flags = AFX_FLAG_PREEMPH | AFX_FLAG_TRIM; kp.fmt = AFX_FMT_F32;
   ClipInfo* d_info = (ClipInfo*)pl->info.p;
   HIP_TRY(hipMemsetAsync(d_info, 0, sizeof(ClipInfo), s));
+  pl->info_clean_n = 0;      // this path leaves the clip records used
   HIP_TRY(launch_trim_blocks(s, pl->samples.p, (const ClipDesc*)pl->clips.p, d_info, (float*)pl->bsum.p, 1, pl->max_tblocks, kp));
   HIP_TRY(launch_trim_decide(s, (const ClipDesc*)pl->clips.p, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, nullptr, 1, kp));
   if (n > 0) {

@@ -93,9 +93,11 @@ constexpr int kStampPhases = 12;
 hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
                       const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax,
                       bool frame_major = false, bool spec = false);
+hipError_t launch_finish(hipStream_t s, ClipInfo* info, int n_clips, int* counters, unsigned* flag_dev, unsigned seq);
+// stats / info_out may be host memory the device can write (the batch's results land where the caller reads them)
 hipError_t launch_stats(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const KParams& kp,
                         const float* mfcc, const float* rms_rows, float* stats, float* frames_out,
-                        const int64_t* frame_offsets, int n_clips);
+                        const int64_t* frame_offsets, int n_clips, ClipInfo* info_out = nullptr);
 hipError_t launch_preemph(hipStream_t s, const float* y, float* out, int64_t n, float b1);
 
 }  // namespace afx

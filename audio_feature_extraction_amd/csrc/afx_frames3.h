@@ -37,6 +37,7 @@ struct F3Tables {
   const int32_t* mel_meta;
   int32_t mel_rounds;
   int32_t mel_wfloats;
+  int32_t mel_all_own;      // every (round, lane) owns a filter: the straight-line schedule stores without an owner test
   uint32_t mel_rp[kF3MaxRounds];   // per round: batches | width << 4 | weight offset (floats) << 8
 };
 

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
   const v2 W1 = {0.92387953251128675613f, -0.38268343236508977173f};      // W16^1
   const v2 W3 = {0.38268343236508977173f, -0.92387953251128675613f};      // W16^3
   const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
-  const float b1 = kp.preemph_b1;
+  const float b1 = pre ? kp.preemph_b1 : 0.f;              // y + 0 * prev = y: interior rows need no select
   const int M = kp.n_mels;
   const int jb = lane ? 128 - lane : 64;
   // image slots (float2 units)
@@ -144,24 +144,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
   };
   const int n_rounds = ft.mel_rounds;
   const int meta0 = MM[lane], meta1 = MM[64 + lane];       // straight-line schedule: the lane's two filters
+  const unsigned mf0 = (meta0 >> 11) & 511, mf1 = (meta1 >> 11) & 511;
   const float amin = kp.amin;
 
   if (nblocks_dev) nblocks = *nblocks_dev;
-  // sum of squares of four rows (one 256-sample sub-block of the pre-emphasised signal), wave-wide; sub-block j of the
-  // clip goes to bsum[base + j] when the clip has such a slot.  A non-finite sum makes the wave look at its rows.
-  auto subblock = [&](float r0, float r1, float r2, float r3, const BlockDesc& bd, int j) {
-    float q = r0 * r0; q = fmaf(r1, r1, q); q = fmaf(r2, r2, q); q = fmaf(r3, r3, q);
-    q += F3_DPP(q, 0xB1); q += F3_DPP(q, 0x4E); q += F3_DPP(q, 0x141); q += F3_DPP(q, 0x140);
-    const int qi = __float_as_int(q);
-    const float t = (__int_as_float(__builtin_amdgcn_readlane(qi, 0)) + __int_as_float(__builtin_amdgcn_readlane(qi, 16))) +
-                    (__int_as_float(__builtin_amdgcn_readlane(qi, 32)) + __int_as_float(__builtin_amdgcn_readlane(qi, 48)));
-    if (j >= 0 && j < bd.pad_[1]) {
-      if (lane == 0) bsum[bd.pad_[0] + j] = t;
-      if (!(fabsf(t) < INFINITY)) {
-        const bool bad = !(isfinite(r0) && isfinite(r1) && isfinite(r2) && isfinite(r3));
-        if (__any(bad) && lane == 0) atomicOr(&info[bd.clip].nonfinite, 1u);
-      }
-    }
+  // Sums of squares of 256-sample sub-blocks of the pre-emphasised signal (four rows each), two at a time: `x` is the
+  // lanes' share of an odd sub-block of the current block (index relative to its first frame), `y` of the even one after
+  // it.  The totals land in lanes `idx`, `idx + 1` of `bs`, one lane per sub-block; the block stores them in one go.
+  float bs = 0.f;
+  unsigned long long bsmask = 0;
+  // Returns true (wave-uniform) when a sum is not finite: the caller then looks at its rows (an overflowing sum of finite
+  // samples is not a non-finite clip).
+  auto sub2 = [&](float x, float y, int idx, unsigned long long two) -> bool {
+    const float m = f3_sum2(x, y);
+    const unsigned long long sel = two << idx;
+    bs = f3_sel(bs, m, sel);
+    bsmask |= sel;
+    return __any(!(fabsf(m) < INFINITY));
+  };
+  auto flag_nonfinite = [&](const BlockDesc& bd, bool bad_rows) {
+    if (__any(bad_rows) && lane == 0) atomicOr(&info[bd.clip].nonfinite, 1u);
+  };
+  auto sub_store = [&](const BlockDesc& bd) {
+    const int j = bd.t0 + lane;
+    if (((bsmask >> lane) & 1) && j < bd.pad_[1]) bsum[bd.pad_[0] + j] = bs;
+    bsmask = 0;
   };
 
   // A wave takes a contiguous run of the block list.  Consecutive blocks of one clip then continue the row pipeline
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
 #pragma unroll
         for (int u = 0; u < 20; ++u) { y[u] = row_ld(sp, 64 * u + lane); yp[u] = row_ld(sp - 1, 64 * u + lane); }
 #pragma unroll
-        for (int u = 0; u < 20; ++u) rows[u] = pre ? f3_pre1(y[u], yp[u], b1) : y[u];
+        for (int u = 0; u < 20; ++u) rows[u] = f3_pre1(y[u], yp[u], b1);
       } else {
 #pragma unroll 1
         for (int u = 0; u < 20; ++u) XB[64 * u + lane] = edge_sample(64 * u + lane);
@@ -237,13 +244,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       if constexpr (SPEC) {
         // rows 8..11 / 12..15 / 16..19 are sub-blocks t0, t0 + 1, t0 + 2 of the clip; the first belongs to the
         // previous block's last pair unless this is the clip's first block
-        if (bd.t0 == 0) subblock(rows[8], rows[9], rows[10], rows[11], bd, 0);
-        subblock(rows[12], rows[13], rows[14], rows[15], bd, bd.t0 + 1);
-        subblock(rows[16], rows[17], rows[18], rows[19], bd, bd.t0 + 2);
+        auto sq4 = [&](int r) { float q = rows[r] * rows[r]; q = fmaf(rows[r + 1], rows[r + 1], q); q = fmaf(rows[r + 2], rows[r + 2], q); return fmaf(rows[r + 3], rows[r + 3], q); };
+        auto bad4 = [&](int r) { return !(isfinite(rows[r]) && isfinite(rows[r + 1]) && isfinite(rows[r + 2]) && isfinite(rows[r + 3])); };
+        if (sub2(sq4(12), sq4(16), 1, 3ull)) flag_nonfinite(bd, bad4(12) || bad4(16));
+        if (bd.t0 == 0 && sub2(0.f, sq4(8), 0, 1ull)) flag_nonfinite(bd, bad4(8));
       }
     }
     float lmax = -INFINITY;
     float* const tile = logmel + bd.frame_slot * (int64_t)M;     // [frame][mel]
+    const bool blk_int = interior(0, 512 * 8 + 768 + 512);       // every row this block (and a chained successor's first pair) loads
 
 #pragma unroll 1
     for (int p = 0; p < npairs; ++p) {
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       for (int i = 0; i < 4; ++i) R[8 + i].x = R[12 + i].y;
       const bool more = p + 1 < npairs || chain;           // the next pair may be the next block's first
       const int jn = 512 * (p + 1) + 768;                  // staged samples [jn, jn + 512)
-      const bool nint = more && interior(jn, jn + 512);
+      const bool nint = more && (blk_int || interior(jn, jn + 512));
 
       // ---- pass 1 + exchange 1
       f3_dft16(z, H, W1, W3);
@@ -367,19 +376,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         const float L01 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(m0.y, amin));
         const float L10 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(m1.x, amin));
         const float L11 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(m1.y, amin));
-        if (meta0 & (1 << 20)) {
-          const unsigned m = (meta0 >> 11) & 511;
-          if (vA) rowA[m] = L00;
-          if (vB) rowA[M + m] = L01;
-          if (vA) lmax = f3_max(lmax, L00);
-          if (vB) lmax = f3_max(lmax, L01);
-        }
-        if (meta1 & (1 << 20)) {
-          const unsigned m = (meta1 >> 11) & 511;
-          if (vA) rowA[m] = L10;
-          if (vB) rowA[M + m] = L11;
-          if (vA) lmax = f3_max(lmax, L10);
-          if (vB) lmax = f3_max(lmax, L11);
+        // every lane owns its two filters here (launch_frames3_w checks), frame A of a pair always exists
+        rowA[mf0] = L00; rowA[mf1] = L10;
+        lmax = f3_max(lmax, f3_max(L00, L10));
+        if (vB) {
+          rowA[M + mf0] = L01; rowA[M + mf1] = L11;
+          lmax = f3_max(lmax, f3_max(L01, L11));
         }
         }
       } else {
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         float n[8];
         if (nint) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) n[u] = pre ? f3_pre1(ny[u], nyp[u], b1) : ny[u];
+          for (int u = 0; u < 8; ++u) n[u] = f3_pre1(ny[u], nyp[u], b1);
         } else {
 #pragma unroll 1
           for (int u = 0; u < 8; ++u) XB[64 * u + lane] = edge_sample(jn + 64 * u + lane);
@@ -431,9 +433,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { R[8 + i].y = n[i]; R[12 + i] = v2{n[i], n[4 + i]}; }
-        if constexpr (SPEC) {          // rows 12..19 of pair p + 1: sub-blocks t0 + 2 (p + 1) + 1, + 2
-          subblock(n[0], n[1], n[2], n[3], bd, bd.t0 + 2 * p + 3);
-          subblock(n[4], n[5], n[6], n[7], bd, bd.t0 + 2 * p + 4);
+        if constexpr (SPEC) {          // rows 12..19 of pair p + 1: sub-blocks t0 + 2 (p + 1) + 1, + 2, as (x, y) = R[12 + i]
+          v2 q = R[12] * R[12]; q = R[13] * R[13] + q; q = R[14] * R[14] + q; q = R[15] * R[15] + q;
+          if (sub2(q.x, q.y, 2 * p + 3, 3ull)) {
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bad |= !isfinite(n[u]);
+            flag_nonfinite(bd, bad);
+          }
         }
       }
     }
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
       const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
       const float mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-      if constexpr (SPEC) { if (lane == 0) blockmax[b] = mx; }
+      if constexpr (SPEC) { if (lane == 0) blockmax[b] = mx; sub_store(bd); }
       else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx)); }
     }
 #ifdef AFX_F3_DEBUG
@@ -675,7 +682,7 @@ static hipError_t launch_frames3_w(hipStream_t s, const void* samples, ClipInfo*
                                    int nblocks, const int* nblocks_dev, const F3Tables& ft, const KParams& kp,
                                    float* logmel, float* blockmax, float* bsum, int* work_ctr, int n_cu) {
   // straight-line mel schedules compiled in: two rounds of width 1
-  const bool two = ft.mel_rounds == 2 && ((ft.mel_rp[0] >> 4) & 15) == 1 && ((ft.mel_rp[1] >> 4) & 15) == 1 &&
+  const bool two = ft.mel_rounds == 2 && ((ft.mel_rp[0] >> 4) & 15) == 1 && ((ft.mel_rp[1] >> 4) & 15) == 1 && ft.mel_all_own &&
                    !getenv("AFX_F3_GENERIC_MEL");
   const int nb0 = ft.mel_rp[0] & 15, nb1 = ft.mel_rp[1] & 15;
   if (two && nb0 == 2 && nb1 == 7)

@@ -160,5 +160,29 @@ __device__ __forceinline__ uint32_t f3_ord(float f) {
 #endif
 #define F3_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, false))
 
+// v[lane] + v[lane ^ 16] and v[lane] + v[lane ^ 32] by gfx950's row / half swaps (one swap + one add each)
+__device__ __forceinline__ float f3_add_xor16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float f3_add_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// d = mask[lane] ? b : a with a wave-uniform 64-bit lane mask (one v_cndmask; the compiler's own code for a lane-indexed
+// bit test is a 64-bit shift, an and and a compare)
+__device__ __forceinline__ float f3_sel(float a, float b, unsigned long long mask) {
+  float d; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(mask)); return d;
+}
+// Two wave-wide sums at once: returns a register whose odd lanes all hold sum(x) and whose even lanes all hold sum(y)
+// (x, y: one addend per lane).  Pairs first, then one register carries both parities through the remaining steps.
+__device__ __forceinline__ float f3_sum2(float x, float y) {
+  x += F3_DPP(x, 0xB1); y += F3_DPP(y, 0xB1);                   // lane ^ 1
+  float m = f3_sel(y, x, 0xAAAAAAAAAAAAAAAAull);
+  m += F3_DPP(m, 0x4E);                                          // lane ^ 2
+  m += F3_DPP(m, 0x124); m += F3_DPP(m, 0x128);                  // row_ror 4, 8: the four quads of a row
+  return f3_add_xor32(f3_add_xor16(m));
+}
+
 
 }  // namespace afx

@@ -1658,13 +1658,15 @@ __global__ __launch_bounds__(256) void k_stats(const ClipDesc* __restrict__ clip
                                                const float* __restrict__ rms_rows,
                                                float* __restrict__ stats,
                                                float* __restrict__ frames_out,
-                                               const int64_t* __restrict__ frame_offsets) {
+                                               const int64_t* __restrict__ frame_offsets,
+                                               ClipInfo* __restrict__ info_out) {
   const int clip = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int K = kp.n_mfcc;
   const int row = blockIdx.x * 4 + wave;
   if (row > K) return;
   const ClipInfo ci = info[clip];
+  if (info_out && row == K && lane == 0) info_out[clip] = ci;      // the caller's copy (host memory the device can write)
   float* st = stats + (int64_t)clip * (4 * K + 3);
   const ClipDesc cd = clips[clip];
   // a clip with fewer than 9 frames fails the MFCC rows (librosa.feature.delta raises) but still has an RMS row:
@@ -1897,10 +1899,26 @@ hipError_t launch_dct(hipStream_t s, const ClipDesc* clips, const ClipInfo* info
 
 hipError_t launch_stats(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const KParams& kp,
                         const float* mfcc, const float* rms_rows, float* stats, float* frames_out,
-                        const int64_t* frame_offsets, int n_clips) {
+                        const int64_t* frame_offsets, int n_clips, ClipInfo* info_out) {
   dim3 grid((kp.n_mfcc + 1 + 3) / 4, n_clips);
   hipLaunchKernelGGL(k_stats, grid, dim3(256), 0, s, clips, info, kp, mfcc, rms_rows, stats, frames_out,
-                     frame_offsets);
+                     frame_offsets, info_out);
+  return hipGetLastError();
+}
+
+// k_finish: the last kernel of a batch.  Clears what the next batch expects cleared (the clip records and the list /
+// ticket counters: two fill commands less in front of every batch), then stores the batch's sequence number to a
+// completion flag in host memory the device can write -- the host can spin on that word instead of asking the
+// runtime (hipEventSynchronize on a stream that already holds the next batch's commands was measured to return late).
+__global__ __launch_bounds__(1024) void k_finish(uint4* info, int n_info16, int* counters, unsigned* flag, unsigned seq) {
+  for (int i = threadIdx.x; i < n_info16; i += 1024) info[i] = uint4{0u, 0u, 0u, 0u};
+  if (counters && threadIdx.x < 4) counters[threadIdx.x] = 0;
+  __syncthreads();
+  if (flag && threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_finish(hipStream_t s, ClipInfo* info, int n_clips, int* counters, unsigned* flag_dev, unsigned seq) {
+  static_assert(sizeof(ClipInfo) == 32, "k_finish clears ClipInfo as two 16-byte words");
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, s, (uint4*)info, n_clips * 2, counters, flag_dev, seq);
   return hipGetLastError();
 }
 

@@ -207,11 +207,18 @@ def main() -> None:
     ap.add_argument("--cpu-clips", type=int, default=1000, help="clips timed on one CPU core (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-pool-seconds", type=float, default=12.0, help="wall-clock budget of the all-core pool sample (0 = skip)")
     ap.add_argument("--no-timing-events", action="store_true")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=1,
                     help="in-flight sub-batches per GPU: the rank's clips are cut into this many runs, each with its "
                          "own context/stream/host thread (what batch_process does), so that one run's bandwidth-bound "
                          "kernels and host round trip overlap another's frame kernel")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="steps in flight on ONE stream (afx_extract_submit / afx_extract_collect, one plan per step in "
+                         "flight, one host thread): every step is a whole-batch pass and the passes run back to back on "
+                         "the device; the host's share of a step (wait, hand-out, next submit) falls under the next "
+                         "step's kernels.  Needs --streams 1")
     args = ap.parse_args()
+    if args.streams > 1:
+        args.inflight = 1          # sub-batches on their own streams: one step at a time each
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
@@ -257,8 +264,9 @@ def main() -> None:
     params = lambda: N.make_params(SR, N_FFT, HOP, N_MFCC, N_MELS)   # noqa: E731
     S = max(1, min(args.streams, n_clips))
     cut = [n_clips * i // S for i in range(S + 1)]
+    D = max(1, args.inflight)
     lanes = []
-    for i in range(S):
+    for i in range(S if D == 1 else 0):
         lo, hi = cut[i], cut[i + 1]
         base = int(offsets[lo])
         end = int(offsets[hi - 1] + lengths[hi - 1])
@@ -268,6 +276,14 @@ def main() -> None:
         dbuf.upload(samples[base:end])
         lanes.append({"ctx": ctx, "plan": plan, "dbuf": dbuf, "offsets": offsets[lo:hi] - base,
                       "lengths": lengths[lo:hi], "out": None})
+
+    if D > 1:                # D plans on one context (one stream), all over the whole batch of one device buffer
+        ctx = N.Context(device)
+        dbuf = N.DeviceBuffer(ctx, samples.nbytes)
+        dbuf.upload(samples)
+        for i in range(D):
+            lanes.append({"ctx": ctx, "plan": N.Plan(ctx, params()), "dbuf": dbuf, "offsets": offsets, "lengths": lengths,
+                          "out": None, "busy": False})
 
     stagger = [0.0]          # seconds between the first submissions of consecutive lanes
 
@@ -299,7 +315,22 @@ def main() -> None:
             ln["thread"] = threading.Thread(target=lane_main, args=(ln,), daemon=True)
             ln["thread"].start()
 
+    step_no = [0]
+
     def run_steps(k):
+        if D > 1:
+            for _ in range(k):
+                ln = lanes[step_no[0] % D]
+                step_no[0] += 1
+                if ln["busy"]:
+                    ln["out"] = ln["plan"].extract_collect()
+                ln["plan"].extract_submit(ln["dbuf"], ln["offsets"], ln["lengths"], out=ln["out"])
+                ln["busy"] = True
+            for ln in lanes:
+                if ln["busy"]:
+                    ln["out"] = ln["plan"].extract_collect()
+                    ln["busy"] = False
+            return
         if S == 1:
             lane_steps(lanes[0], k)
             return
@@ -319,9 +350,11 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(1)
+    run_steps(D)
     t_w = time.perf_counter()
-    if S > 1:
+    if D > 1:
+        pass
+    elif S > 1:
         lanes[0]["done"].clear(); lanes[0]["q"].put((3, 0.0)); lanes[0]["done"].wait()
     else:
         lane_steps(lanes[0], 3)
@@ -331,13 +364,13 @@ def main() -> None:
     run_steps(max(args.warmup, 8))
     for ln in lanes:
         assert int((ln["out"]["status"] != 0).sum()) == 0, "synthetic clips must all succeed"
-    frames_per_step = int(sum(int(ln["out"]["nframes"].sum()) for ln in lanes))
+    frames_per_step = int(sum(int(ln["out"]["nframes"].sum()) for ln in (lanes[:1] if D > 1 else lanes)))
 
     # PCIe-inclusive rate (host float32 -> stats), reported beside the HBM-resident value
     h0 = time.perf_counter()
-    lanes[0]["plan"].extract_batch(samples[:int(offsets[cut[1] - 1] + lengths[cut[1] - 1])], offsets[:cut[1]], lengths[:cut[1]])
+    hres = lanes[0]["plan"].extract_batch(samples[:int(offsets[cut[1] - 1] + lengths[cut[1] - 1])], offsets[:cut[1]], lengths[:cut[1]])
     host_dt = time.perf_counter() - h0
-    host_frames = int(lanes[0]["out"]["nframes"].sum())
+    host_frames = int(hres["nframes"].sum())
 
     # The frame kernel alone on the GPU: the WHOLE batch on one stream, a few launches outside the timed region
     # (a separate context; the same figure a single-stream rocprofv3 kernel trace of this command gives).
@@ -365,7 +398,7 @@ def main() -> None:
         xb.free(); xp.close(); xc.close()
     if not args.no_timing_events:
         for ln in lanes:
-            ln["plan"].set_timing(True)
+            ln["plan"].set_timing(True, frames_only=True)      # one event pair per step: the kernel the roofline is about
             ln["plan"].timings(reset=True)
     fence()
     t0 = time.perf_counter()
@@ -424,7 +457,8 @@ def main() -> None:
                     "note": ("avg_launch_ms = union of the launch intervals of all %d streams (HIP events, common device clock) "
                              "/ launches: GPU time inside the kernel, <= ms_per_step; sum_of_launch_ms counts overlapped time "
                              "once per stream; 'exclusive' = the whole batch on one stream" % S),
-                    "kernels_ms_per_step": {k: v[0] / args.steps for k, v in kt.items()}}
+                    "inflight": D,
+                    "kernels_ms_per_step": {k: v[0] / args.steps for k, v in kt.items() if v[1] > 0}}
         line = {
             "metric": f"audio frames/sec (sr={SR}, n_fft={N_FFT}, hop={HOP}, n_mfcc={N_MFCC})",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -434,7 +468,8 @@ def main() -> None:
                                    f"n_mfcc={N_MFCC}, n_mels={N_MELS}, hamming, pre-emphasis 0.97 + trim 30 dB + RMS "
                                    f"(BASELINE configs[{cfg['baseline_index'] if world == 1 or args.config != 2 else 3}])",
                        "clips_per_gpu": n_clips, "frames_per_gpu_step": frames_per_step,
-                       "parallelism": f"file-shard x{world}, no collective; {S} in-flight sub-batches per GPU",
+                       "parallelism": (f"file-shard x{world}, no collective; {S} in-flight sub-batches per GPU" if D == 1 else
+                                       f"file-shard x{world}, no collective; {D} whole-batch steps in flight on one stream (submit / collect)"),
                        "input": "HBM-resident float32"},
             "roofline": roof,
             "cpu_baseline": cpu,
@@ -448,8 +483,9 @@ def main() -> None:
         for ln in lanes:
             ln["thread"].join()
     for ln in lanes:
-        ln["dbuf"].free()
         ln["plan"].close()
+    for ln in (lanes[:1] if D > 1 else lanes):
+        ln["dbuf"].free()
         ln["ctx"].close()
     if distributed:
         dist.barrier()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AFX_VERSION 101
+#define AFX_VERSION 102
 
 typedef enum afx_status {
   AFX_OK = 0,
@@ -152,6 +152,22 @@ int afx_extract_batch(afx_plan* plan,
                       int64_t* out_trim, int32_t* out_nframes,
                       float* out_frames, const int64_t* frame_offsets);
 
+/* The same pass in two halves, for callers that keep the device busy across batches (batch_process walks its
+ * files in windows, F:204-211): afx_extract_submit queues everything a batch needs -- kernels and the copies of its
+ * results -- on the plan's stream and returns; afx_extract_collect waits for THAT batch only and fills the out_*
+ * arrays given at submit (which, like `samples`, `offsets` and `lengths`, must stay valid until then).  Two plans of
+ * one context submitted alternately from one thread run back to back on the device: the host's share of a batch
+ * (collect, hand-out, next submit) falls under the other plan's kernels.  One batch per plan may be pending; n_clips
+ * must be in [1, 32768]; afx_extract_batch(plan, ...) == submit + collect per 32768-clip chunk. */
+int afx_extract_submit(afx_plan* plan,
+                       const void* samples, int sample_fmt, int mem_kind,
+                       const int64_t* offsets, const int64_t* lengths, int n_clips,
+                       int flags,
+                       float* out_stats, int32_t* out_status,
+                       int64_t* out_trim, int32_t* out_nframes,
+                       float* out_frames, const int64_t* frame_offsets);
+int afx_extract_collect(afx_plan* plan);
+
 /* extract_f0 (F:76-114): librosa.pyin(y, fmin, fmax, frame_length=n_fft, hop_length=hop, sr)
  * at librosa's defaults, of the same preprocessed clips (flags as for
  * afx_extract_batch: the reference feeds y_processed, F:195), reduced as F:97-107.
@@ -226,6 +242,8 @@ enum {
   AFX_K_STATS = 4,         /* delta/delta2 + per-clip statistics */
   AFX_K_COUNT = 5
 };
+/* enable: 0 off, 1 every kernel, 2 the frame kernel (AFX_K_FRAMES) only -- an event pair per kernel costs stream time
+ * (about 5 us each, more with several batches in flight), so a throughput run times the one kernel it reports */
 int afx_plan_set_timing(afx_plan* plan, int enable);
 int afx_plan_get_timings(afx_plan* plan, float* ms_sum /*[AFX_K_COUNT]*/,
                          int32_t* launches /*[AFX_K_COUNT]*/, int reset);
