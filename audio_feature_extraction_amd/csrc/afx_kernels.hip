@@ -1690,31 +1690,66 @@ __global__ __launch_bounds__(256) void k_stats(const ClipDesc* __restrict__ clip
     for (int t = lane; t < T; t += 64) s += (double)x[t];
     const double mean = wave_sum_d(s) * invT;
     const float meanf = (float)mean;
-    double s2 = 0.0, sd1 = 0.0, sd2 = 0.0;
+    double s2 = 0.0;
+    if (!fo) {
+#pragma unroll 8
+      for (int t = lane; t < T; t += 64) { const float d = x[t] - meanf; s2 += (double)d * (double)d; }
+    } else {
 #pragma unroll 2
-    for (int t = lane; t < T; t += 64) {
-      const float d = x[t] - meanf;
-      s2 += (double)d * (double)d;
-      // savgol_filter(width 9, polyorder=deriv=order, mode='interp'): interior taps; the
-      // fitted edge polynomial has a constant derivative, so frames 0..3 / T-4..T-1 repeat
-      // frame 4 / frame T-5.
-      const int tc = t < 4 ? 4 : (t > T - 5 ? T - 5 : t);
-      const float* c = x + tc;
-      const double d1 = (4.0 * ((double)c[4] - (double)c[-4]) + 3.0 * ((double)c[3] - (double)c[-3]) +
-                         2.0 * ((double)c[2] - (double)c[-2]) + ((double)c[1] - (double)c[-1])) * (1.0 / 60.0);
-      const double d2 = (28.0 * ((double)c[4] + (double)c[-4]) + 7.0 * ((double)c[3] + (double)c[-3]) -
-                         8.0 * ((double)c[2] + (double)c[-2]) - 17.0 * ((double)c[1] + (double)c[-1]) -
-                         20.0 * (double)c[0]) * (1.0 / 462.0);
-      const float d1f = (float)d1, d2f = (float)d2;
-      sd1 += (double)d1f; sd2 += (double)d2f;
-      if (fo) {
+      for (int t = lane; t < T; t += 64) {
+        const float d = x[t] - meanf;
+        s2 += (double)d * (double)d;
+        // savgol_filter(width 9, polyorder=deriv=order, mode='interp'): interior taps; the
+        // fitted edge polynomial has a constant derivative, so frames 0..3 / T-4..T-1 repeat
+        // frame 4 / frame T-5.
+        const int tc = t < 4 ? 4 : (t > T - 5 ? T - 5 : t);
+        const float* c = x + tc;
+        const double d1 = (4.0 * ((double)c[4] - (double)c[-4]) + 3.0 * ((double)c[3] - (double)c[-3]) +
+                           2.0 * ((double)c[2] - (double)c[-2]) + ((double)c[1] - (double)c[-1])) * (1.0 / 60.0);
+        const double d2 = (28.0 * ((double)c[4] + (double)c[-4]) + 7.0 * ((double)c[3] + (double)c[-3]) -
+                           8.0 * ((double)c[2] + (double)c[-2]) - 17.0 * ((double)c[1] + (double)c[-1]) -
+                           20.0 * (double)c[0]) * (1.0 / 462.0);
         fo[(int64_t)row * fstride + t] = x[t];
-        fo[(int64_t)(K + row) * fstride + t] = d1f;
-        fo[(int64_t)(2 * K + row) * fstride + t] = d2f;
+        fo[(int64_t)(K + row) * fstride + t] = (float)d1;
+        fo[(int64_t)(2 * K + row) * fstride + t] = (float)d2;
       }
     }
-    s2 = wave_sum_d(s2); sd1 = wave_sum_d(sd1); sd2 = wave_sum_d(sd2);
+    s2 = wave_sum_d(s2);
     if (lane == 0) {
+      // Means of the two delta rows without the rows: both filters are differences, so their sum over the frames
+      // telescopes to the nine frames at either end (the first filter) and the second one's weights cancel the bulk of
+      // the row exactly (28 + 7 - 8 - 17 = 10 on either side of -20).  Frames 0..3 and T-4..T-1 repeat frame 4 / T-5.
+      double h[9], g[9];                                  // h[i] = x[i], g[i] = x[T - 9 + i]
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { h[i] = (double)x[i]; g[i] = (double)x[T - 9 + i]; }
+      auto D1 = [](const double* c) {
+        return (4.0 * (c[4] - c[-4]) + 3.0 * (c[3] - c[-3]) + 2.0 * (c[2] - c[-2]) + (c[1] - c[-1])) * (1.0 / 60.0);
+      };
+      auto D2 = [](const double* c) {
+        return (28.0 * (c[4] + c[-4]) + 7.0 * (c[3] + c[-3]) - 8.0 * (c[2] + c[-2]) - 17.0 * (c[1] + c[-1]) - 20.0 * c[0]) * (1.0 / 462.0);
+      };
+      const double w2[5] = {0.0, -17.0, -8.0, 7.0, 28.0};
+      double sd1 = 0.0, sd2 = 0.0;
+#pragma unroll
+      for (int k = 1; k <= 4; ++k) {
+        double head = 0.0, tail = 0.0, hl = 0.0, hr = 0.0, tl = 0.0, tr = 0.0;
+#pragma unroll
+        for (int i = 4 - k; i <= 3 + k; ++i) head += h[i];          // x[4 - k .. 3 + k]
+#pragma unroll
+        for (int i = 5 - k; i <= 4 + k; ++i) tail += g[i];          // x[T - 4 - k .. T - 5 + k]
+#pragma unroll
+        for (int i = 4 - k; i <= 3; ++i) hl += h[i];
+#pragma unroll
+        for (int i = 4; i <= 3 + k; ++i) hr += h[i];
+#pragma unroll
+        for (int i = 5 - k; i <= 4; ++i) tl += g[i];
+#pragma unroll
+        for (int i = 5; i <= 4 + k; ++i) tr += g[i];
+        sd1 += (double)k * (tail - head);
+        sd2 += w2[k] * ((hl - hr) + (tr - tl));
+      }
+      sd1 = sd1 * (1.0 / 60.0) + 4.0 * ((double)(float)D1(h + 4) + (double)(float)D1(g + 4));
+      sd2 = sd2 * (1.0 / 462.0) + 4.0 * ((double)(float)D2(h + 4) + (double)(float)D2(g + 4));
       st[row] = meanf;
       st[K + row] = (float)sqrt(s2 * invT);
       st[2 * K + row] = (float)(sd1 * invT);

@@ -216,6 +216,9 @@ def main() -> None:
                          "flight, one host thread): every step is a whole-batch pass and the passes run back to back on "
                          "the device; the host's share of a step (wait, hand-out, next submit) falls under the next "
                          "step's kernels.  Needs --streams 1")
+    ap.add_argument("--queue", choices=("shared", "own"), default="own",
+                    help="with --inflight > 1: the steps in flight share one stream (back to back) or have one each "
+                         "(the tail of one step's frame kernel under the start of the next)")
     args = ap.parse_args()
     if args.streams > 1:
         args.inflight = 1          # sub-batches on their own streams: one step at a time each
@@ -281,8 +284,12 @@ def main() -> None:
         ctx = N.Context(device)
         dbuf = N.DeviceBuffer(ctx, samples.nbytes)
         dbuf.upload(samples)
+        ctxs = [ctx]
         for i in range(D):
-            lanes.append({"ctx": ctx, "plan": N.Plan(ctx, params()), "dbuf": dbuf, "offsets": offsets, "lengths": lengths,
+            c = ctx if args.queue == "shared" else N.Context(device)
+            if c is not ctx:
+                ctxs.append(c)
+            lanes.append({"ctx": c, "plan": N.Plan(c, params()), "dbuf": dbuf, "offsets": offsets, "lengths": lengths,
                           "out": None, "busy": False})
 
     stagger = [0.0]          # seconds between the first submissions of consecutive lanes
@@ -469,7 +476,7 @@ def main() -> None:
                                    f"(BASELINE configs[{cfg['baseline_index'] if world == 1 or args.config != 2 else 3}])",
                        "clips_per_gpu": n_clips, "frames_per_gpu_step": frames_per_step,
                        "parallelism": (f"file-shard x{world}, no collective; {S} in-flight sub-batches per GPU" if D == 1 else
-                                       f"file-shard x{world}, no collective; {D} whole-batch steps in flight on one stream (submit / collect)"),
+                                       f"file-shard x{world}, no collective; {D} whole-batch steps in flight on {'one stream' if args.queue == 'shared' else 'their own streams'} (submit / collect)"),
                        "input": "HBM-resident float32"},
             "roofline": roof,
             "cpu_baseline": cpu,
@@ -484,9 +491,14 @@ def main() -> None:
             ln["thread"].join()
     for ln in lanes:
         ln["plan"].close()
-    for ln in (lanes[:1] if D > 1 else lanes):
-        ln["dbuf"].free()
-        ln["ctx"].close()
+    if D > 1:
+        lanes[0]["dbuf"].free()
+        for c in ctxs[1:] + ctxs[:1]:
+            c.close()
+    else:
+        for ln in lanes:
+            ln["dbuf"].free()
+            ln["ctx"].close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
