@@ -62,10 +62,10 @@ size_t frames3s_lds_bytes(int waves, const F3Tables& ft);
 size_t frames3d_lds_bytes(int waves, const F3Tables& ft);
 hipError_t launch_frames3s(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                            const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
-                           float* blockmax, float* bsum, bool spec, int n_cu);
+                           float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu);
 hipError_t launch_frames3d(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                            const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
-                           float* blockmax, float* bsum, bool spec, int n_cu);
+                           float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu);
 // spectral descriptors (k_frames3s<DESC>): librosa.feature.spectral_contrast's octave bands as bin ranges [lo, hi] of the
 // sub-band and the number of magnitudes averaged at either end
 struct SpecBands {

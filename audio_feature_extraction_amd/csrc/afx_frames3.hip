@@ -178,21 +178,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
 #ifdef AFX_F3_DEBUG
   const unsigned long long stamp1 = wall_clock64();
 #endif
-  // Which runs: with a work counter (the speculative launch), about half of the list is dealt out up front, C0 blocks per
-  // wave, and the rest is taken by ticket in runs that shrink (C0 / 2, C0 / 3, then single blocks).  The four waves of a
-  // SIMD do not advance at one speed (the issue arbiter favours the oldest: measured 615 .. 900 us for equal static
-  // shares), so equal shares leave the SIMDs under-occupied for the last third of the launch; tickets let the waves
-  // that run ahead take more.  Without a counter (the short list launch): equal contiguous shares.
-  int b_lo, b_hi, dyn0 = 0, cA = 1, cB = 1;
-  if (work_ctr) {
-    const int C0 = nblocks / (2 * total_waves);
-    b_lo = wg * C0; b_hi = b_lo + C0; dyn0 = total_waves * C0;
-    cA = C0 / 2 > 1 ? C0 / 2 : 1; cB = C0 / 3 > 1 ? C0 / 3 : 1;
-  } else {
-    b_lo = (int)((int64_t)wg * nblocks / total_waves); b_hi = (int)((int64_t)(wg + 1) * nblocks / total_waves);
-  }
-  for (;;) {                                              // the runs of this wave
-  for (int b = b_lo; b < b_hi; ++b) {
+  F3Runs runs = f3_runs_init(work_ctr, nblocks, total_waves, wg, true);     // afx_frames3_dev.h: shares, then tickets
+  do {                                                    // the runs of this wave
+  const int b_hi = runs.b_hi;
+  for (int b = runs.b_lo; b < b_hi; ++b) {
     BlockDesc bd = blocks[b];
     if (!bd.active) continue;
     bool first = true;                                    // first block of a run: its 20 rows are loaded; later ones inherit them
@@ -464,17 +453,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     bd = blocks[b];
     }
   }
-  if (!work_ctr) break;
-  int t = 0;
-  if (lane == 0) t = atomicAdd(work_ctr, 1);
-  t = __builtin_amdgcn_readfirstlane(t);
-  int c = 1;
-  if (t < total_waves) { b_lo = dyn0 + cA * t; c = cA; }
-  else if (t < 2 * total_waves) { b_lo = dyn0 + cA * total_waves + cB * (t - total_waves); c = cB; }
-  else b_lo = dyn0 + (cA + cB) * total_waves + (t - 2 * total_waves);
-  if (b_lo >= nblocks) break;
-  b_hi = b_lo + c < nblocks ? b_lo + c : nblocks;
-  }
+  } while (f3_runs_next(runs, work_ctr, nblocks, lane));
 #ifdef AFX_F3_DEBUG
   if (SPEC && lane == 0 && wg < 8192) {
     g_f3_stamps[4 * wg] = stamp0; g_f3_stamps[4 * wg + 1] = stamp1; g_f3_stamps[4 * wg + 2] = wall_clock64();
@@ -646,8 +625,8 @@ bool frames3_eligible(const KParams& kp, const F3Tables& ft) {
 hipError_t launch_frames3_any(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                               const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
                               float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu) {
-  if (kp.n_fft == 2048) return launch_frames3s(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, spec, n_cu);
-  if (kp.n_fft == 512) return launch_frames3d(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, spec, n_cu);
+  if (kp.n_fft == 2048) return launch_frames3s(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, spec, work_ctr, n_cu);
+  if (kp.n_fft == 512) return launch_frames3d(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, spec, work_ctr, n_cu);
   return launch_frames3(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, spec, work_ctr, n_cu);
 }
 

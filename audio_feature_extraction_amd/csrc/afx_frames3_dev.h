@@ -158,6 +158,44 @@ __device__ __forceinline__ uint32_t f3_ord(float f) {
 #else
 #define F3_SKIP(bit) false
 #endif
+// Which blocks a wave works on.  With a work counter (a zeroed device int), about half of the block list is dealt out up
+// front, C0 consecutive blocks per wave, and the rest is taken by ticket in runs that shrink (C0 / 2, C0 / 3, then single
+// blocks): the four waves of a SIMD do not advance at one speed (the issue arbiter favours the oldest; 615 .. 900 us were
+// measured for equal shares of k_frames3), so equal shares leave the SIMDs under-occupied for the last third of a
+// launch, while one ticket per block makes every wave queue on one L2 atomic (79 000 of them slowed the 512 / 128
+// kernel by 60 %).  Without a counter (the short list launch): blocks wg, wg + waves, ...
+struct F3Runs {
+  int b_lo, b_hi, stride, dyn0, cA, cB, waves;
+};
+__device__ __forceinline__ F3Runs f3_runs_init(const int* work_ctr, int nblocks, int total_waves, int wg, bool contiguous) {
+  F3Runs r;
+  r.waves = total_waves; r.stride = 1; r.dyn0 = 0; r.cA = 1; r.cB = 1;
+  if (work_ctr) {
+    const int C0 = nblocks / (2 * total_waves);
+    r.b_lo = wg * C0; r.b_hi = r.b_lo + C0; r.dyn0 = total_waves * C0;
+    r.cA = C0 / 2 > 1 ? C0 / 2 : 1; r.cB = C0 / 3 > 1 ? C0 / 3 : 1;
+  } else if (contiguous) {
+    r.b_lo = (int)((long long)wg * nblocks / total_waves); r.b_hi = (int)((long long)(wg + 1) * nblocks / total_waves);
+  } else {
+    r.b_lo = wg; r.b_hi = nblocks; r.stride = total_waves;
+  }
+  return r;
+}
+// the wave's next run; false when the list is exhausted (wave-uniform)
+__device__ __forceinline__ bool f3_runs_next(F3Runs& r, int* work_ctr, int nblocks, int lane) {
+  if (!work_ctr) return false;
+  int t = 0;
+  if (lane == 0) t = atomicAdd(work_ctr, 1);
+  t = __builtin_amdgcn_readfirstlane(t);
+  int c = 1;
+  if (t < r.waves) { r.b_lo = r.dyn0 + r.cA * t; c = r.cA; }
+  else if (t < 2 * r.waves) { r.b_lo = r.dyn0 + r.cA * r.waves + r.cB * (t - r.waves); c = r.cB; }
+  else r.b_lo = r.dyn0 + (r.cA + r.cB) * r.waves + (t - 2 * r.waves);
+  if (r.b_lo >= nblocks) return false;
+  r.b_hi = r.b_lo + c < nblocks ? r.b_lo + c : nblocks;
+  return true;
+}
+
 #define F3_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, false))
 
 // v[lane] + v[lane ^ 16] and v[lane] + v[lane ^ 32] by gfx950's row / half swaps (one swap + one add each)

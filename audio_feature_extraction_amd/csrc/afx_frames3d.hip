@@ -35,7 +35,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
                                                          F3Tables ft, KParams kp,
                                                          float* __restrict__ logmel,
                                                          float* __restrict__ blockmax,
-                                                         float* __restrict__ bsum) {
+                                                         float* __restrict__ bsum, int* __restrict__ work_ctr) {
   constexpr int N = 512, HOP = 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -117,7 +117,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
   };
 
   const int total_waves = gridDim.x * WAVES;
-  for (int b = blockIdx.x * WAVES + wave; b < nblocks; b += total_waves) {
+  F3Runs runs = f3_runs_init(work_ctr, nblocks, total_waves, blockIdx.x * WAVES + wave, false);
+  do {
+  for (int b = runs.b_lo; b < runs.b_hi; b += runs.stride) {
     const BlockDesc bd = blocks[b];
     if (!bd.active) continue;
     const int Tleft = bd.T - bd.t0;
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
       else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx)); }
     }
   }
+  } while (f3_runs_next(runs, work_ctr, nblocks, lane));
 }
 
 int frames3d_waves(const F3Tables& ft) {
@@ -288,7 +291,7 @@ int frames3d_waves(const F3Tables& ft) {
 template <int FMT, int WAVES, bool SPEC>
 static hipError_t launch_frames3d_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
                                     int nblocks, const int* nblocks_dev, const F3Tables& ft, const KParams& kp,
-                                    float* logmel, float* blockmax, float* bsum, int n_cu) {
+                                    float* logmel, float* blockmax, float* bsum, int* work_ctr, int n_cu) {
   static bool attr_set[64] = {};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -301,17 +304,17 @@ static hipError_t launch_frames3d_t(hipStream_t s, const void* samples, ClipInfo
   }
   const int grid = std::max(1, std::min(n_cu, (nblocks + WAVES - 1) / WAVES));
   hipLaunchKernelGGL((k_frames3d<FMT, WAVES, SPEC>), dim3(grid), dim3(WAVES * 64), frames3d_lds_bytes(WAVES, ft), s,
-                     samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum);
+                     samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr);
   return hipGetLastError();
 }
 
 hipError_t launch_frames3d(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                            const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
-                           float* blockmax, float* bsum, bool spec, int n_cu) {
+                           float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu) {
   const int waves = frames3d_waves(ft);
 #define AFX_F3D_GO(FMT, W)                                                                                                    \
-  (spec ? launch_frames3d_t<FMT, W, true>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu) \
-        : launch_frames3d_t<FMT, W, false>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu))
+  (spec ? launch_frames3d_t<FMT, W, true>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu) \
+        : launch_frames3d_t<FMT, W, false>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu))
   if (kp.fmt == AFX_FMT_S16) return waves == 16 ? AFX_F3D_GO(AFX_FMT_S16, 16) : AFX_F3D_GO(AFX_FMT_S16, 12);
   return waves == 16 ? AFX_F3D_GO(AFX_FMT_F32, 16) : AFX_F3D_GO(AFX_FMT_F32, 12);
 #undef AFX_F3D_GO

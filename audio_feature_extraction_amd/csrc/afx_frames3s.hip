@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
                                                          float* __restrict__ bsum,
                                                          float* __restrict__ desc_out,
                                                          const int64_t* __restrict__ desc_offs,
-                                                         SpecBands sb) {
+                                                         SpecBands sb, int* __restrict__ work_ctr) {
   constexpr int N = 2048, HOP = 512;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -132,7 +132,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
   };
 
   const int total_waves = gridDim.x * WAVES;
-  for (int b = blockIdx.x * WAVES + wave; b < nblocks; b += total_waves) {
+  F3Runs runs = f3_runs_init(work_ctr, nblocks, total_waves, blockIdx.x * WAVES + wave, false);
+  do {
+  for (int b = runs.b_lo; b < runs.b_hi; b += runs.stride) {
     const BlockDesc bd = blocks[b];
     if (!bd.active) continue;
     const int Tleft = bd.T - bd.t0;
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
       else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx)); }
     }
   }
+  } while (f3_runs_next(runs, work_ctr, nblocks, lane));
 }
 
 int frames3s_waves(const F3Tables& ft) {
@@ -405,7 +408,7 @@ int frames3s_waves(const F3Tables& ft) {
 template <int FMT, int WAVES, bool SPEC>
 static hipError_t launch_frames3s_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
                                     int nblocks, const int* nblocks_dev, const F3Tables& ft, const KParams& kp,
-                                    float* logmel, float* blockmax, float* bsum, int n_cu) {
+                                    float* logmel, float* blockmax, float* bsum, int* work_ctr, int n_cu) {
   static bool attr_set[64] = {};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -418,7 +421,7 @@ static hipError_t launch_frames3s_t(hipStream_t s, const void* samples, ClipInfo
   }
   const int grid = std::max(1, std::min(n_cu, (nblocks + WAVES - 1) / WAVES));
   hipLaunchKernelGGL((k_frames3s<FMT, WAVES, SPEC, false>), dim3(grid), dim3(WAVES * 64), frames3s_lds_bytes(WAVES, ft), s,
-                     samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, nullptr, nullptr, SpecBands{});
+                     samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, nullptr, nullptr, SpecBands{}, work_ctr);
   return hipGetLastError();
 }
 
@@ -438,7 +441,7 @@ static hipError_t launch_spectral_t(hipStream_t s, const void* samples, ClipInfo
   }
   const int grid = std::max(1, std::min(n_cu, (nblocks + 11) / 12));
   hipLaunchKernelGGL((k_frames3s<FMT, 12, false, true>), dim3(grid), dim3(12 * 64), frames3s_lds_bytes(12, ft), s,
-                     samples, info, blocks, nblocks, nullptr, ft, kp, nullptr, nullptr, nullptr, desc_out, desc_offs, sb);
+                     samples, info, blocks, nblocks, nullptr, ft, kp, nullptr, nullptr, nullptr, desc_out, desc_offs, sb, nullptr);
   return hipGetLastError();
 }
 
@@ -451,11 +454,11 @@ hipError_t launch_spectral(hipStream_t s, const void* samples, ClipInfo* info, c
 
 hipError_t launch_frames3s(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                            const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
-                           float* blockmax, float* bsum, bool spec, int n_cu) {
+                           float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu) {
   const int waves = frames3s_waves(ft);
 #define AFX_F3S_GO(FMT, W)                                                                                                    \
-  (spec ? launch_frames3s_t<FMT, W, true>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu) \
-        : launch_frames3s_t<FMT, W, false>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, n_cu))
+  (spec ? launch_frames3s_t<FMT, W, true>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu) \
+        : launch_frames3s_t<FMT, W, false>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu))
   if (kp.fmt == AFX_FMT_S16) return waves == 16 ? AFX_F3S_GO(AFX_FMT_S16, 16) : AFX_F3S_GO(AFX_FMT_S16, 12);
   return waves == 16 ? AFX_F3S_GO(AFX_FMT_F32, 16) : AFX_F3S_GO(AFX_FMT_F32, 12);
 #undef AFX_F3S_GO
