@@ -1899,6 +1899,79 @@ hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
   }
 }
 
+// k_dct16l<NCG>: k_dct16 for more than 16 coefficients (NCG = 2, 3).  There the coefficient images are 64 / 96 registers
+// per lane, re-read from memory by every wave for every 16-frame tile (96 loads in front of 96 MFMAs: 0.30 ms for the
+// 40 coefficients of the 16 kHz configuration, against 0.13 ms of spill traffic).  Here a workgroup copies the images
+// to LDS once (NCG x 8 KB), walks many tiles of its clip, and fetches each MFMA's A operand with one ds_read_b32;
+// the next tile's frames are in flight while the current one is multiplied.
+template <int NCG, bool FM>
+__global__ __launch_bounds__(256) void k_dct16l(const ClipDesc* __restrict__ clips,
+                                                const ClipInfo* __restrict__ info,
+                                                const float* __restrict__ dctP, KParams kp,
+                                                const float* __restrict__ logmel,
+                                                float* __restrict__ mfcc, int spec) {
+  extern __shared__ float dct_tab[];                     // [(g S + s) 4 + c][64 lanes]
+  const int clip = blockIdx.y;
+  const ClipInfo ci = info[clip];
+  if (ci.status != AFX_CLIP_OK) return;                  // uniform per workgroup
+  const int M = kp.n_mels, K = kp.n_mfcc, S = M >> 4;    // S <= 8
+  for (int i = threadIdx.x; i < NCG * S * 4 * 64; i += 256) dct_tab[i] = dctP[i];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const ClipDesc cd = clips[clip];
+  const float theta = ord2f(ci.lmax_ord) - kp.top_db;
+  const int f = lane & 15, q = lane >> 4;
+  const int ntiles = (ci.T + 15) >> 4, tstep = gridDim.x * 4;
+  const int g0 = spec ? (int)(ci.start / kp.hop) : 0;
+  auto load_tile = [&](int tile, float4 (&x)[8]) {
+    const int t0 = tile * 16;
+    const float* src = FM ? logmel + (cd.frame_base + g0 + t0 + f) * (int64_t)M + q * 4
+                          : logmel + (cd.frame_base + t0) * (int64_t)M + (q * 16 + f) * 4;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      x[s] = (s < S && tile < ntiles) ? *reinterpret_cast<const float4*>(src + s * (FM ? 16 : 256)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  float4 xc[8], xn[8];
+  int tile = blockIdx.x * 4 + wave;
+  load_tile(tile, xc);
+  for (; tile < ntiles; tile += tstep) {
+    load_tile(tile + tstep, xn);
+    f32x4 acc[NCG][2];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < S) {
+        const float b0 = fmaxf(xc[s].x, theta), b1 = fmaxf(xc[s].y, theta);
+        const float b2 = fmaxf(xc[s].z, theta), b3 = fmaxf(xc[s].w, theta);
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+          const float* a = dct_tab + ((g * S + s) * 4) * 64 + lane;
+          acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0, acc[g][0], 0, 0, 0);
+          acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[64], b1, acc[g][1], 0, 0, 0);
+          acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[128], b2, acc[g][0], 0, 0, 0);
+          acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[192], b3, acc[g][1], 0, 0, 0);
+        }
+      }
+    }
+    const int t0 = tile * 16;
+    if (t0 + f < ci.T) {
+      float* out = mfcc + cd.frame_base * (int64_t)K + t0 + f;
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        const f32x4 r4 = acc[g][0] + acc[g][1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = g * 16 + q * 4 + r;
+          if (k < K) out[(int64_t)k * cd.tpad] = r4[r];
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) xc[s] = xn[s];
+  }
+}
+
 template <bool FM>
 static hipError_t launch_dct_t(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb,
                                const KParams& kp, const float* logmel, float* mfcc, int n_clips, int max_tmax, int spec) {
@@ -1906,8 +1979,17 @@ static hipError_t launch_dct_t(hipStream_t s, const ClipDesc* clips, const ClipI
     dim3 g16(((max_tmax + 15) / 16 + 4 * kDctTiles - 1) / (4 * kDctTiles), n_clips);
     const int ncg = (kp.n_mfcc + 15) / 16;
     if (ncg == 1) hipLaunchKernelGGL((k_dct16<1, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
-    else if (ncg == 2) hipLaunchKernelGGL((k_dct16<2, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
-    else hipLaunchKernelGGL((k_dct16<3, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
+    else {
+      // a workgroup per 64 tiles of a clip (16 per wave): the table copy is paid once per 512 KB of frames
+      const int tiles = (max_tmax + 15) / 16;
+      dim3 gl(std::max(1, (tiles + 63) / 64), n_clips);
+      const size_t lds = (size_t)ncg * (kp.n_mels / 16) * 4 * 64 * sizeof(float);
+      if (getenv("AFX_NO_DCT16L")) {
+        if (ncg == 2) hipLaunchKernelGGL((k_dct16<2, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
+        else hipLaunchKernelGGL((k_dct16<3, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
+      } else if (ncg == 2) hipLaunchKernelGGL((k_dct16l<2, FM>), gl, dim3(256), lds, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
+      else hipLaunchKernelGGL((k_dct16l<3, FM>), gl, dim3(256), lds, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
+    }
     return hipGetLastError();
   }
   dim3 grid(((max_tmax + 15) / 16 + 3) / 4, n_clips);
