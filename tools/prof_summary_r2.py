@@ -32,7 +32,7 @@ for cfg in (2, 3, 5):
     tr = os.path.join(root, f"cfg{cfg}_trace")
     if not os.path.isdir(tr):
         continue
-    print(f"== config {cfg}: kernel stats, single stream (rocprofv3 --kernel-trace --stats; bench.py --config {cfg} --steps 20 --warmup 3 --cpu-clips 0 --streams 1) ==")
+    print(f"== config {cfg}: kernel stats, single stream (rocprofv3 --kernel-trace --stats; bench.py --config {cfg} --steps 20 --warmup 3 --cpu-clips 0 --streams 1 --inflight 1) ==")
     rows = kernel_stats(tr)
     with open(os.path.join(root, f"cfg{cfg}_kernel_stats.csv"), "w") as fh:
         for r in rows:
@@ -45,7 +45,7 @@ for cfg in (2, 3, 5):
                 k = row.get("Kernel_Name", "")
                 if "afx" in k:
                     acc[short(k)][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    lines = [f"== config {cfg}: PMC, per-dispatch average (separate rocprofv3 --pmc passes; bench.py --config {cfg} --steps 5 --warmup 2 --cpu-clips 0 --streams 1) =="]
+    lines = [f"== config {cfg}: PMC, per-dispatch average (separate rocprofv3 --pmc passes; bench.py --config {cfg} --steps 5 --warmup 2 --cpu-clips 0 --streams 1 --inflight 1) =="]
     for k in sorted(acc):
         lines.append(k)
         for c in sorted(acc[k]):
@@ -64,7 +64,7 @@ for cfg in (2, 3, 5):
             per_kernel[k] = {"fetch_bytes_x2": fe, "write_bytes": wr}
     algo = frames * 4.0 * hop
     tj = {"round": 2, "config": cfg,
-          "source": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/profile_r2.sh), single stream: one launch of every kernel per step",
+          "source": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/profile_r2.sh), one step in flight: one launch of every kernel per step",
           "correction": "gfx950: FETCH_SIZE counts half the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact; KB -> bytes",
           "per_kernel_bytes_per_launch": per_kernel,
           "algorithmic_bytes_per_step": algo}
@@ -80,11 +80,11 @@ for cfg in (2, 3, 5):
     with open(os.path.join(root, f"cfg{cfg}_traffic.json"), "w") as fh:
         json.dump(tj, fh, indent=1)
     print(json.dumps({k: tj[k] for k in ("pipeline_hbm_bytes_per_step", "algorithmic_bytes_per_step", "pipeline_over_algorithmic")}))
-s3 = os.path.join(root, "cfg2_streams3_trace")
+s3 = os.path.join(root, "cfg2_default_trace")
 if os.path.isdir(s3):
-    print("== config 2: kernel stats, default 3 streams (bench.py --steps 20 --warmup 3 --cpu-clips 0) ==")
+    print("== config 2: kernel stats, the default run: two steps in flight on their own streams (bench.py --steps 20 --warmup 3 --cpu-clips 0) ==")
     rows = kernel_stats(s3)
-    with open(os.path.join(root, "cfg2_streams3_kernel_stats.csv"), "w") as fh:
+    with open(os.path.join(root, "cfg2_default_kernel_stats.csv"), "w") as fh:
         for r in rows:
             fh.write(",".join(r) + "\n")
             print(",".join(r))
