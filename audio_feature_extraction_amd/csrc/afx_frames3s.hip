@@ -135,10 +135,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
   F3Runs runs = f3_runs_init(work_ctr, nblocks, total_waves, blockIdx.x * WAVES + wave, false);
   do {
   for (int b = runs.b_lo; b < runs.b_hi; b += runs.stride) {
-    const BlockDesc bd = blocks[b];
+    BlockDesc bd = blocks[b];
     if (!bd.active) continue;
+    // consecutive blocks of one clip inside a run continue the row pipeline across the block boundary (4 new rows, as
+    // inside a block) instead of re-loading 16: no halo re-read, no exposed load latency at a block's start
+    bool first = true;
+    v2 R[16];
+    for (;;) {                                            // the chained blocks
     const int Tleft = bd.T - bd.t0;
     const int nfr = Tleft >= 16 ? 16 : Tleft;
+    bool chain = false;
+    if (SPEC && nfr == 16 && runs.stride == 1 && b + 1 < runs.b_hi) {
+      const BlockDesc* nx = blocks + b + 1;
+      chain = nx->active && nx->clip == bd.clip && nx->t0 == bd.t0 + 16;
+    }
     const int64_t sbase = bd.sample_base;
     const sample_t* const sp = (const sample_t*)samples + sbase;
     auto interior = [&](int j0, int j1) -> bool {
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
     };
 
     // ---- rows of the first frame: staged samples [0, 2048)
-    v2 R[16];
+    if (first) {
     if (interior(0, N)) {
       float x0[16], x1[16], xp[16];
 #pragma unroll
@@ -185,6 +195,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
       if (bd.t0 == 0) subblock(R[8], R[9], R[10], R[11], bd, 0);
       subblock(R[12], R[13], R[14], R[15], bd, bd.t0 + 1);
     }
+    }
     float lmax = -INFINITY;
     float* const tile = logmel + bd.frame_slot * (int64_t)M;     // [frame][mel]
 
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
       for (int u = 0; u < 16; ++u) z[u] = R[u] * ldv(WT + u * 64 + lane);
 #pragma unroll
       for (int u = 0; u < 12; ++u) R[u] = R[u + 4];
-      const bool more = f + 1 < nfr;
+      const bool more = f + 1 < nfr || chain;              // the next frame may be the next block's first
       const int jn = HOP * f + N;                          // the next frame's 4 new rows: staged samples [jn, jn + 512)
       const bool nint = more && interior(jn, jn + HOP);
 
@@ -394,6 +405,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
       if constexpr (DESC) { (void)mx; }
       else if constexpr (SPEC) { if (lane == 0) blockmax[b] = mx; }
       else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx)); }
+    }
+    if (!chain) break;
+    first = false;
+    ++b;
+    bd = blocks[b];
     }
   }
   } while (f3_runs_next(runs, work_ctr, nblocks, lane));
