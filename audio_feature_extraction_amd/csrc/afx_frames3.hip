@@ -75,6 +75,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
                                                         int* __restrict__ work_ctr) {
   constexpr int N = 1024, HOP = 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (nblocks_dev) {                       // the list launch: an empty list (nothing was trimmed) costs no table set-up
+    nblocks = *nblocks_dev;
+    if (nblocks <= 0) return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef AFX_F3_DEBUG
@@ -147,7 +151,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
   const unsigned mf0 = (meta0 >> 11) & 511, mf1 = (meta1 >> 11) & 511;
   const float amin = kp.amin;
 
-  if (nblocks_dev) nblocks = *nblocks_dev;
   // Sums of squares of 256-sample sub-blocks of the pre-emphasised signal (four rows each), two at a time: `x` is the
   // lanes' share of an odd sub-block of the current block (index relative to its first frame), `y` of the even one after
   // it.  The totals land in lanes `idx`, `idx + 1` of `bs`, one lane per sub-block; the block stores them in one go.

@@ -38,6 +38,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
                                                          float* __restrict__ bsum, int* __restrict__ work_ctr) {
   constexpr int N = 512, HOP = 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (nblocks_dev) {                       // the list launch: an empty list (nothing was trimmed) costs no table set-up
+    nblocks = *nblocks_dev;
+    if (nblocks <= 0) return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lp = lane & 31, half = lane >> 5;
@@ -95,7 +99,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
   };
   const int n_rounds = ft.mel_rounds;
   const float amin = kp.amin;
-  if (nblocks_dev) nblocks = *nblocks_dev;
 
   // sums of squares of four rows over the wave; `upper`: the upper half-wave's total (its rows are the pass's new sub-blocks)
   auto rowsum4 = [&](float r0, float r1, float r2, float r3, bool upper, bool& bad) -> float {

@@ -49,6 +49,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
                                                          SpecBands sb, int* __restrict__ work_ctr) {
   constexpr int N = 2048, HOP = 512;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (nblocks_dev) {                       // the list launch: an empty list (nothing was trimmed) costs no table set-up
+    nblocks = *nblocks_dev;
+    if (nblocks <= 0) return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* const tabs = smem + WAVES * kF3ExFloats;
@@ -111,7 +115,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
   };
   const int n_rounds = ft.mel_rounds;
   const float amin = kp.amin;
-  if (nblocks_dev) nblocks = *nblocks_dev;
 
   // sum of squares of four float2 rows (one 512-sample sub-block of the pre-emphasised signal), wave-wide
   auto subblock = [&](v2 r0, v2 r1, v2 r2, v2 r3, const BlockDesc& bd, int j) {

@@ -1685,43 +1685,43 @@ __global__ __launch_bounds__(256) void k_stats(const ClipDesc* __restrict__ clip
   const int64_t fstride = cd.tmax;
   if (row < K) {
     const float* x = mfcc + cd.frame_base * (int64_t)K + (int64_t)row * cd.tpad;
-    double s = 0.0;
+    // the nine frames at either end, for the delta means below: fetched now, one per lane, handed to lane 0 later
+    const float ev = x[lane < 9 ? lane : (lane < 18 ? T - 18 + lane : 0)];
+    // one pass: sum and sum of squares in float64 (values up to ~1e3, T ~ 1e3: the squares' sum is exact to 1e-8 of
+    // a variance term of 1e4 or more); sum (x - c)^2 = ss - 2 c s + T c^2 about the float32 mean c, as numpy's std
+    double s = 0.0, ss = 0.0;
 #pragma unroll 8
-    for (int t = lane; t < T; t += 64) s += (double)x[t];
-    const double mean = wave_sum_d(s) * invT;
+    for (int t = lane; t < T; t += 64) { const double v = (double)x[t]; s += v; ss = fma(v, v, ss); }
+    s = wave_sum_d(s); ss = wave_sum_d(ss);
+    const double mean = s * invT;
     const float meanf = (float)mean;
-    double s2 = 0.0;
-    if (!fo) {
-#pragma unroll 8
-      for (int t = lane; t < T; t += 64) { const float d = x[t] - meanf; s2 += (double)d * (double)d; }
-    } else {
+    const double c = (double)meanf;
+    const double s2 = fmax(ss - 2.0 * c * s + (double)T * c * c, 0.0);
+    if (fo) {
 #pragma unroll 2
       for (int t = lane; t < T; t += 64) {
-        const float d = x[t] - meanf;
-        s2 += (double)d * (double)d;
         // savgol_filter(width 9, polyorder=deriv=order, mode='interp'): interior taps; the
         // fitted edge polynomial has a constant derivative, so frames 0..3 / T-4..T-1 repeat
         // frame 4 / frame T-5.
         const int tc = t < 4 ? 4 : (t > T - 5 ? T - 5 : t);
-        const float* c = x + tc;
-        const double d1 = (4.0 * ((double)c[4] - (double)c[-4]) + 3.0 * ((double)c[3] - (double)c[-3]) +
-                           2.0 * ((double)c[2] - (double)c[-2]) + ((double)c[1] - (double)c[-1])) * (1.0 / 60.0);
-        const double d2 = (28.0 * ((double)c[4] + (double)c[-4]) + 7.0 * ((double)c[3] + (double)c[-3]) -
-                           8.0 * ((double)c[2] + (double)c[-2]) - 17.0 * ((double)c[1] + (double)c[-1]) -
-                           20.0 * (double)c[0]) * (1.0 / 462.0);
+        const float* cc = x + tc;
+        const double d1 = (4.0 * ((double)cc[4] - (double)cc[-4]) + 3.0 * ((double)cc[3] - (double)cc[-3]) +
+                           2.0 * ((double)cc[2] - (double)cc[-2]) + ((double)cc[1] - (double)cc[-1])) * (1.0 / 60.0);
+        const double d2 = (28.0 * ((double)cc[4] + (double)cc[-4]) + 7.0 * ((double)cc[3] + (double)cc[-3]) -
+                           8.0 * ((double)cc[2] + (double)cc[-2]) - 17.0 * ((double)cc[1] + (double)cc[-1]) -
+                           20.0 * (double)cc[0]) * (1.0 / 462.0);
         fo[(int64_t)row * fstride + t] = x[t];
         fo[(int64_t)(K + row) * fstride + t] = (float)d1;
         fo[(int64_t)(2 * K + row) * fstride + t] = (float)d2;
       }
     }
-    s2 = wave_sum_d(s2);
-    if (lane == 0) {
-      // Means of the two delta rows without the rows: both filters are differences, so their sum over the frames
-      // telescopes to the nine frames at either end (the first filter) and the second one's weights cancel the bulk of
-      // the row exactly (28 + 7 - 8 - 17 = 10 on either side of -20).  Frames 0..3 and T-4..T-1 repeat frame 4 / T-5.
-      double h[9], g[9];                                  // h[i] = x[i], g[i] = x[T - 9 + i]
+    // Means of the two delta rows without the rows: both filters are differences, so their sum over the frames
+    // telescopes to the nine frames at either end (the first filter) and the second one's weights cancel the bulk of
+    // the row exactly (28 + 7 - 8 - 17 = 10 on either side of -20).  Frames 0..3 and T-4..T-1 repeat frame 4 / T-5.
+    double h[9], g[9];                                    // h[i] = x[i], g[i] = x[T - 9 + i]
 #pragma unroll
-      for (int i = 0; i < 9; ++i) { h[i] = (double)x[i]; g[i] = (double)x[T - 9 + i]; }
+    for (int i = 0; i < 9; ++i) { h[i] = (double)__shfl(ev, i); g[i] = (double)__shfl(ev, 9 + i); }
+    if (lane == 0) {
       auto D1 = [](const double* c) {
         return (4.0 * (c[4] - c[-4]) + 3.0 * (c[3] - c[-3]) + 2.0 * (c[2] - c[-2]) + (c[1] - c[-1])) * (1.0 / 60.0);
       };
