@@ -170,3 +170,14 @@ def test_lifter_scales_the_dct_rows():
     f = (1 + (22.0 / 2) * np.sin(np.pi * n / 22.0)).astype(np.float32)      # librosa.feature.mfcc(lifter=22)
     np.testing.assert_allclose(d1, d0 * f[:, None], rtol=2e-7)
     assert f[0] > 1.5 and abs(f[10] - (1 + 11 * np.sin(np.pi * 11 / 22))) < 1e-5      # n = 11 = L / 2: factor 1 + L / 2
+
+
+def test_bench_interval_union():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.union_ms([]) == 0.0
+    assert abs(bench.union_ms([(0.0, 1.0), (0.5, 2.0), (3.0, 3.5)]) - 2.5) < 1e-12
+    assert abs(bench.union_ms([(2.0, 3.0), (0.0, 1.0), (0.25, 0.5)]) - 2.0) < 1e-12
+    assert 1 <= bench.usable_cpus() <= (os.cpu_count() or 1)
