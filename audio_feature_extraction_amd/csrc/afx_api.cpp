@@ -47,7 +47,7 @@ struct afx_plan {
   F3Tables f3{};              // k_frames3 (n_fft 1024 / hop 256): mel schedule + twiddle source
   bool use_f3 = false;
   std::vector<void*> table_allocs;
-  DevBuf samples, clips, info, blocks, bsum, logmel, rms, mfcc, stats, frames, frame_offs, stamps;
+  DevBuf samples, clips, info, blocks, bsum, logmel, rms, mfcc, frames, frame_offs, stamps;     // statistics go straight to h_pin
   DevBuf blocks_spec, blockmax, items, n_items;      // speculative pipeline (k_frames3 before the trim decision)
   std::vector<BlockDesc> h_blocks;
   // extract_f0 (pYIN): tables for the last (fmin, fmax) used and the stage's workspace
@@ -309,7 +309,7 @@ extern "C" void afx_plan_destroy(afx_plan* pl) {
   release(pl->f0_bin); release(pl->f0_prob); release(pl->f0_ptr); release(pl->f0_best); release(pl->f0_lprob); release(pl->f0_lu); release(pl->f0_states); release(pl->f0_stats);
   release(pl->f0_out); release(pl->f0_offs);
   release(pl->samples); release(pl->clips); release(pl->info); release(pl->blocks); release(pl->bsum);
-  release(pl->logmel); release(pl->rms); release(pl->mfcc); release(pl->stats); release(pl->frames);
+  release(pl->logmel); release(pl->rms); release(pl->mfcc); release(pl->frames);
   release(pl->frame_offs); release(pl->stamps);
   release(pl->blocks_spec); release(pl->blockmax); release(pl->items); release(pl->n_items);
   if (pl->h_pin) (void)hipHostFree(pl->h_pin);
@@ -481,7 +481,6 @@ static int chunk_enqueue(afx_plan* pl, const void* samples, int fmt, int mem_kin
   if ((rc = ensure(pl->logmel, (size_t)pl->total_tpad * M * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->rms, (size_t)pl->total_tpad * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->mfcc, (size_t)pl->total_tpad * K * sizeof(float))) != AFX_OK) return rc;
-  if ((rc = ensure(pl->stats, (size_t)n * nstat * sizeof(float))) != AFX_OK) return rc;
   // Per-frame output: this chunk's clips occupy [f_lo, f_hi) of the caller's buffer.  The device copy holds exactly that
   // range (offsets rebased), so that a later chunk never touches -- or copies stale device memory over -- an earlier one's rows.
   float* d_frames = nullptr;
