@@ -28,6 +28,7 @@ SYMBOLS = (
     "afx_malloc", "afx_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
     "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables", "afx_build_mel_schedule",
     "afx_extract_batch", "afx_extract_submit", "afx_extract_collect", "afx_f0_batch", "afx_zcr_batch", "afx_spectral_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings", "afx_plan_get_intervals",
+    "afx_wav_probe", "afx_wav_read_s16",
 )
 
 
@@ -90,8 +91,46 @@ def lib() -> C.CDLL:
         L.afx_plan_set_timing.argtypes = [vp, i32]
         L.afx_plan_get_timings.argtypes = [vp, vp, vp, i32]
         L.afx_plan_get_intervals.argtypes = [vp, i32, vp, vp, i32, i32p]
+        L.afx_wav_probe.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+        L.afx_wav_read_s16.argtypes = [vp, i32, i32, vp, vp, vp, C.c_int64, vp, vp]
         _lib = L
     return _lib
+
+
+def _path_array(paths):
+    arr = (C.c_char_p * len(paths))()
+    arr[:] = [os.fsencode(p) for p in paths]
+    return arr
+
+
+def wav_probe(paths, threads: int = 16) -> dict:
+    """Host-only: RIFF headers of many files at once (native threads).  tag 1 = PCM, 3 = float; status 0 ok,
+    1 not a usable WAVE file, 2 cannot be opened."""
+    n = len(paths)
+    info = np.zeros((n, 4), np.int32)
+    frames, off, status = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int32)
+    if n:
+        arr = _path_array(paths)
+        _check(lib().afx_wav_probe(arr, n, int(threads), info.ctypes.data, frames.ctypes.data, off.ctypes.data,
+                                   status.ctypes.data), "afx_wav_probe")
+    return {"tag": info[:, 0], "channels": info[:, 1], "rate": info[:, 2], "bits": info[:, 3],
+            "frames": frames, "data_off": off, "status": status}
+
+
+def wav_read_s16(paths, data_off, frames, out: np.ndarray, offsets, threads: int = 16) -> np.ndarray:
+    """Host-only: the 16-bit samples of the files straight into ``out`` (int16, C-contiguous) at ``offsets``."""
+    n = len(paths)
+    status = np.zeros(n, np.int32)
+    if n:
+        if out.dtype != np.int16 or not out.flags.c_contiguous:
+            raise ValueError("out must be C-contiguous int16")
+        data_off = np.ascontiguousarray(data_off, np.int64)
+        frames = np.ascontiguousarray(frames, np.int64)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        arr = _path_array(paths)
+        _check(lib().afx_wav_read_s16(arr, n, int(threads), data_off.ctypes.data, frames.ctypes.data, out.ctypes.data,
+                                      int(out.size), offsets.ctypes.data, status.ctypes.data), "afx_wav_read_s16")
+    return status
 
 
 def f0_build_tables(sr: int, n_fft: int, hop: int, fmin: float, fmax: float) -> dict:

@@ -1,0 +1,136 @@
+// Host-side ingest for batch_process: RIFF/WAVE headers of many files parsed, and the samples of the files that need
+// no conversion (16-bit PCM) read straight into the caller's packed batch buffer, by native threads.
+// (reference: AudioFeatureExtractor.load_audio, core/feature_extractor.py:52 -> librosa.load -> soundfile; the chunk walk
+// and its error cases are those of audio_feature_extraction_amd/wavio.py: _parse / read_wav_raw, which remains the
+// decoder of every other sample type and of files these entry points reject.)
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "afx.h"
+#include "afx_internal.h"
+
+namespace {
+
+struct WavHead {
+  int32_t tag = 0, channels = 0, rate = 0, bits = 0;
+  int64_t data_off = 0, data_bytes = 0;
+};
+
+inline uint32_t rd32(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint32_t rd16(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+bool pread_all(int fd, void* dst, size_t n, int64_t off) {
+  char* d = (char*)dst;
+  while (n > 0) {
+    const ssize_t r = ::pread(fd, d, n, (off_t)off);
+    if (r <= 0) return false;
+    d += r; n -= (size_t)r; off += r;
+  }
+  return true;
+}
+
+// the chunk walk of wavio._parse: first `fmt ` chunk seen before the first `data` chunk; a data chunk longer than the
+// file is cut at the file's end; chunks are word-aligned.  0 = ok, 1 = not a WAVE file / malformed
+int parse_head(int fd, int64_t fsize, WavHead& h) {
+  unsigned char b[64];
+  if (fsize < 12 || !pread_all(fd, b, 12, 0) || std::memcmp(b, "RIFF", 4) != 0 || std::memcmp(b + 8, "WAVE", 4) != 0) return 1;
+  int64_t pos = 12;
+  bool have_fmt = false;
+  while (pos + 8 <= fsize) {
+    if (!pread_all(fd, b, 8, pos)) return 1;
+    const uint32_t size = rd32(b + 4);
+    const int64_t body = pos + 8;
+    if (std::memcmp(b, "fmt ", 4) == 0) {
+      if (size < 16) return 1;
+      const size_t want = (size_t)std::min<int64_t>(std::min<uint32_t>(size, 40), fsize - body);
+      if (want < 16 || !pread_all(fd, b, want, body)) return 1;
+      h.tag = (int32_t)rd16(b); h.channels = (int32_t)rd16(b + 2); h.rate = (int32_t)rd32(b + 4); h.bits = (int32_t)rd16(b + 14);
+      if (h.tag == 0xFFFE && size >= 40 && want >= 26) h.tag = (int32_t)rd16(b + 24);     // WAVE_FORMAT_EXTENSIBLE: the sub-format's first word
+      have_fmt = true;
+    } else if (std::memcmp(b, "data", 4) == 0) {
+      if (!have_fmt) return 1;
+      h.data_off = body;
+      h.data_bytes = std::min<int64_t>((int64_t)size, fsize - body);
+      return 0;
+    }
+    pos = body + (int64_t)size + (size & 1);
+  }
+  return 1;
+}
+
+template <typename F>
+void run_threads(int n, int threads, F&& job) {
+  const int T = std::max(1, std::min(threads, n));
+  if (T == 1) { for (int i = 0; i < n; ++i) job(i); return; }
+  std::atomic<int> next{0};
+  std::vector<std::thread> pool;
+  pool.reserve(T);
+  for (int t = 0; t < T; ++t)
+    pool.emplace_back([&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) job(i); });
+  for (auto& th : pool) th.join();
+}
+
+}  // namespace
+
+extern "C" int afx_wav_probe(const char* const* paths, int n, int threads, int32_t* info, int64_t* frames,
+                             int64_t* data_off, int32_t* status) {
+  if (n < 0 || (n > 0 && (!paths || !info || !frames || !data_off || !status))) {
+    afx::set_error("afx_wav_probe: null/invalid argument");
+    return AFX_ERR_INVALID;
+  }
+  run_threads(n, threads, [&](int i) {
+    info[4 * i] = info[4 * i + 1] = info[4 * i + 2] = info[4 * i + 3] = 0;
+    frames[i] = 0; data_off[i] = 0; status[i] = 2;
+    const int fd = paths[i] ? ::open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
+    if (fd < 0) return;
+    struct stat st;
+    WavHead h;
+    if (::fstat(fd, &st) == 0 && parse_head(fd, (int64_t)st.st_size, h) == 0) {
+      info[4 * i] = h.tag; info[4 * i + 1] = h.channels; info[4 * i + 2] = h.rate; info[4 * i + 3] = h.bits;
+      const int64_t bpf = (int64_t)(h.bits / 8) * h.channels;
+      if (h.channels >= 1 && bpf > 0) {
+        frames[i] = h.data_bytes / bpf;
+        data_off[i] = h.data_off;
+        status[i] = 0;
+      } else {
+        status[i] = 1;
+      }
+    } else {
+      status[i] = 1;
+    }
+    ::close(fd);
+  });
+  return AFX_OK;
+}
+
+extern "C" int afx_wav_read_s16(const char* const* paths, int n, int threads, const int64_t* data_off,
+                                const int64_t* frames, int16_t* out, int64_t out_len, const int64_t* offsets,
+                                int32_t* status) {
+  if (n < 0 || (n > 0 && (!paths || !data_off || !frames || !out || !offsets || !status))) {
+    afx::set_error("afx_wav_read_s16: null/invalid argument");
+    return AFX_ERR_INVALID;
+  }
+  for (int i = 0; i < n; ++i)
+    if (frames[i] < 0 || offsets[i] < 0 || offsets[i] + frames[i] > out_len) {
+      afx::set_error("afx_wav_read_s16: a clip does not fit the output buffer");
+      return AFX_ERR_INVALID;
+    }
+  run_threads(n, threads, [&](int i) {
+    status[i] = 2;
+    const int fd = paths[i] ? ::open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
+    if (fd < 0) return;
+    if (frames[i] == 0 || pread_all(fd, out + offsets[i], (size_t)frames[i] * sizeof(int16_t), data_off[i])) status[i] = 0;
+    ::close(fd);
+  });
+  return AFX_OK;
+}

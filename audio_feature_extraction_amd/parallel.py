@@ -158,50 +158,98 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
             errors[i] = e
             return None
 
+    # Files that need no conversion -- 16-bit PCM, mono, at the target rate: what a corpus of speech clips is -- never
+    # pass through Python: libafx parses their headers and reads their samples straight into the packed int16 batch
+    # buffer with native threads (afx_wav_probe / afx_wav_read_s16).  Everything else, and any file the native reader
+    # cannot open or parse, goes through wavio as before (which also produces the error a bad file is logged with).
+    native_threads = max(1, min(os.cpu_count() or 1, DECODE_THREADS_PER_GPU * len(devices)) // max(1, min(len(lanes), 4)))
+    win_pool = ThreadPoolExecutor(max(1, len(lanes)))
+
+    def load_window(win):
+        """-> (packed 16-bit group or None, indices decoded by wavio, their decoded clips)"""
+        rest = list(win)
+        packed = None
+        try:
+            paths = [str(files[i]) for i in win]
+            pr = _native.wav_probe(paths, native_threads)
+            ok = ((pr["status"] == 0) & (pr["tag"] == 1) & (pr["bits"] == 16) & (pr["channels"] == 1) &
+                  (pr["rate"] == extractor.sr))
+            sel = np.nonzero(ok)[0]
+            if sel.size:
+                lens = pr["frames"][sel].astype(np.int64)
+                padded = (lens + 3) // 4 * 4                      # 4-element alignment, as _pack
+                offs = np.zeros(sel.size, np.int64)
+                offs[1:] = np.cumsum(padded)[:-1]
+                buf = np.empty(max(int(padded.sum()), 1), np.int16)
+                st = _native.wav_read_s16([paths[j] for j in sel], pr["data_off"][sel], lens, buf, offs, native_threads)
+                for o, ln, pd in zip(offs[padded > lens], lens[padded > lens], padded[padded > lens]):
+                    buf[o + ln: o + pd] = 0
+                good = st == 0
+                if good.any():
+                    packed = ([win[j] for j in sel[good]], buf, offs[good], lens[good])
+                    taken = set(packed[0])
+                    rest = [i for i in win if i not in taken]
+        except Exception:                                         # no native reader: the Python decoder takes the window
+            rest, packed = list(win), None
+        decoded = list(pool.map(dec, rest)) if rest else []
+        return packed, rest, decoded
+
+    def run_group(plan, cur, buf, offs, lens, fmt):
+        dbuf = plan.device_buffer(max(buf.nbytes, 16))            # one PCIe copy for both passes
+        try:
+            dbuf.upload(buf)
+            out = plan.extract_batch(dbuf, offs, lens, flags=flags, fmt=fmt)
+            f0 = plan.f0_batch(dbuf, offs, lens, extractor.f0_min, extractor.f0_max, flags=flags, fmt=fmt)
+            stats[cur] = out["stats"]
+            nframes[cur] = out["nframes"]
+            f0s[cur] = f0["stats"]
+            f0_done[cur] = True
+            status[cur] = out["status"]                           # last: a file counts only with both passes done
+        finally:
+            dbuf.free()
+
     def worker(lane, idxs):
         wins = _windows(sizes, idxs, max_batch_samples)
-        pending = [pool.submit(dec, i) for i in wins[0]] if wins else []
+        pending = win_pool.submit(load_window, wins[0]) if wins else None
         plan = None
         for k, win in enumerate(wins):
             t0 = time.perf_counter()
-            decoded = [f.result() for f in pending]
-            # next window decodes while this one is on the device
-            pending = [pool.submit(dec, i) for i in wins[k + 1]] if k + 1 < len(wins) else []
+            packed, rest, decoded = pending.result()
+            # next window loads while this one is on the device
+            pending = win_pool.submit(load_window, wins[k + 1]) if k + 1 < len(wins) else None
             t1 = time.perf_counter()
-            cur: List[int] = []
             try:
                 if plan is None:
                     plan = extractor._plan(lane[0], lane[1])
+                if packed is not None:                            # the natively packed 16-bit clips, in budget-sized runs
+                    ids, buf, offs, lens = packed
+                    pos = 0
+                    while pos < len(ids):
+                        tot, end = 0, pos
+                        while end < len(ids) and (end == pos or tot + int(lens[end]) <= max_batch_samples):
+                            tot += int(lens[end])
+                            end += 1
+                        lo = int(offs[pos])
+                        hi = int(offs[end - 1] + (lens[end - 1] + 3) // 4 * 4)
+                        run_group(plan, ids[pos:end], buf[lo:hi], offs[pos:end] - lo, lens[pos:end], _native.FMT_S16)
+                        pos = end
                 for kind, fmt, dt in (("s16", _native.FMT_S16, np.int16), ("f32", _native.FMT_F32, np.float32)):
-                    sel = [(i, d[1]) for i, d in zip(win, decoded) if d is not None and d[0] == kind]
+                    sel = [(i, d[1]) for i, d in zip(rest, decoded) if d is not None and d[0] == kind]
                     pos = 0
                     while pos < len(sel):          # a window may still exceed the budget (sizes were estimates)
                         tot, end = 0, pos
                         while end < len(sel) and (end == pos or tot + sel[end][1].size <= max_batch_samples):
                             tot += sel[end][1].size
                             end += 1
-                        cur = [i for i, _ in sel[pos:end]]
                         buf, offs, lens = _pack([y for _, y in sel[pos:end]], dt)
-                        dbuf = plan.device_buffer(max(buf.nbytes, 16))       # one PCIe copy for both passes
-                        try:
-                            dbuf.upload(buf)
-                            out = plan.extract_batch(dbuf, offs, lens, flags=flags, fmt=fmt)
-                            f0 = plan.f0_batch(dbuf, offs, lens, extractor.f0_min, extractor.f0_max, flags=flags, fmt=fmt)
-                            stats[cur] = out["stats"]
-                            nframes[cur] = out["nframes"]
-                            f0s[cur] = f0["stats"]
-                            f0_done[cur] = True
-                            status[cur] = out["status"]          # last: a file counts only with both passes done
-                        finally:
-                            dbuf.free()
-                        cur = []
+                        run_group(plan, [i for i, _ in sel[pos:end]], buf, offs, lens, fmt)
                         pos = end
             except Exception as e:          # a device-level failure drops the files of the sub-batch it hit, and the
                 for i in win:               # rest of this window; later windows are still attempted
                     if errors[i] is None and not (status[i] >= 0 and f0_done[i]):
                         errors[i] = e
                         status[i] = -1
-            del decoded
+            del decoded, packed
             with phase_lock:
                 phase["decode_wait"] += t1 - t0
                 phase["device"] += time.perf_counter() - t1
@@ -211,6 +259,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
         t.start()
     for t in threads:
         t.join()
+    win_pool.shutdown()
     pool.shutdown()
 
     t_gpu = time.perf_counter()

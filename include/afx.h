@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AFX_VERSION 102
+#define AFX_VERSION 103
 
 typedef enum afx_status {
   AFX_OK = 0,
@@ -222,6 +222,18 @@ int afx_spectral_batch(afx_plan* plan,
  * Any pointer may be NULL. */
 int afx_f0_build_tables(int sr, int n_fft, int hop, double fmin, double fmax, int32_t* info,
                         double* beta, double* lt, double* freqs);
+
+/* Host-only ingest for batch_process (load_audio, F:52 -> librosa.load -> soundfile), by `threads` native threads.
+ * afx_wav_probe walks the RIFF chunks of n files: info[4 i ..] = format tag (1 PCM, 3 IEEE float; the sub-format of
+ * WAVE_FORMAT_EXTENSIBLE), channels, sample rate, bits per sample; frames[i], data_off[i] = sample frames and byte offset
+ * of the data chunk (cut at the file's end); status[i] = 0 ok, 1 not a usable RIFF/WAVE file, 2 cannot be opened / read.
+ * afx_wav_read_s16 copies frames[i] 16-bit samples of file i from data_off[i] to out[offsets[i] ..] (for files the probe
+ * found to be 16-bit PCM mono: a batch packed in place, uploaded as AFX_FMT_S16); status[i] = 0 or 2.  Every other sample
+ * type, channel count or rate goes through the caller's own decoder. */
+int afx_wav_probe(const char* const* paths, int n, int threads, int32_t* info /*[4n]*/, int64_t* frames,
+                  int64_t* data_off, int32_t* status);
+int afx_wav_read_s16(const char* const* paths, int n, int threads, const int64_t* data_off, const int64_t* frames,
+                     int16_t* out, int64_t out_len, const int64_t* offsets, int32_t* status);
 
 /* preprocess_audio(y) (F:58-74): pre-emphasis + trim of ONE host clip.
  * out_y receives the n pre-emphasised samples (host, n floats); the kept span

@@ -1,4 +1,5 @@
 """RIFF/WAVE decode (the decode+mono half of librosa.load, feature_extractor.py:52)."""
+import os
 import struct
 
 import numpy as np
@@ -111,3 +112,66 @@ def test_resample_swept_sine_and_identity():
     assert np.sqrt(np.mean(late ** 2)) < 1e-4
     same = wavio.resample(y, 22050, 22050)
     assert same is y or np.array_equal(same, y)
+
+
+def _riff(fmt_body: bytes, data: bytes, extra_before_data: bytes = b"", declared=None) -> bytes:
+    import struct
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt_body)) + fmt_body + extra_before_data
+    body += b"data" + struct.pack("<I", len(data) if declared is None else declared) + data
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def test_native_probe_and_read_agree_with_the_python_decoder(tmp_path):
+    """afx_wav_probe / afx_wav_read_s16 (batch_process's ingest of 16-bit PCM) against wavio on the cases its chunk walk
+    has: plain PCM16, an odd-sized LIST chunk before the data, WAVE_FORMAT_EXTENSIBLE, a data chunk longer than the file,
+    stereo, 8-bit, float32, garbage, a missing file."""
+    import struct
+    from audio_feature_extraction_amd import _native as N
+    rng = np.random.default_rng(3)
+    pcm = (rng.standard_normal(1001) * 8000).astype("<i2")
+    fmt16 = struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16)
+    ext = struct.pack("<HHIIHH", 0xFFFE, 1, 16000, 32000, 2, 16) + struct.pack("<HHI", 22, 16, 4) + struct.pack("<H", 1) + b"\x00" * 14
+    files = {
+        "plain.wav": _riff(fmt16, pcm.tobytes()),
+        "list.wav": _riff(fmt16, pcm.tobytes(), extra_before_data=b"LIST" + struct.pack("<I", 5) + b"abcde\x00"),
+        "ext.wav": _riff(ext, pcm.tobytes()),
+        "long.wav": _riff(fmt16, pcm.tobytes(), declared=10 * pcm.nbytes),
+        "stereo.wav": _riff(struct.pack("<HHIIHH", 1, 2, 16000, 64000, 4, 16), np.repeat(pcm, 2).tobytes()),
+        "u8.wav": _riff(struct.pack("<HHIIHH", 1, 1, 16000, 16000, 1, 8), (pcm.astype(np.int32) // 256 + 128).astype(np.uint8).tobytes()),
+        "f32.wav": _riff(struct.pack("<HHIIHH", 3, 1, 16000, 64000, 4, 32), (pcm / 32768.0).astype("<f4").tobytes()),
+        "junk.wav": b"not a wav file at all",
+        "nofmt.wav": b"RIFF" + struct.pack("<I", 4 + 8 + pcm.nbytes) + b"WAVE" + b"data" + struct.pack("<I", pcm.nbytes) + pcm.tobytes(),
+    }
+    paths = []
+    for name, blob in files.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        paths.append(str(p))
+    paths.append(str(tmp_path / "missing.wav"))
+    pr = N.wav_probe(paths, threads=4)
+    for i, p in enumerate(paths):
+        try:
+            a, rate, kind = wavio.read_wav_raw(p)
+        except FileNotFoundError:
+            assert pr["status"][i] == 2, p
+            continue
+        except wavio.WavError:
+            assert pr["status"][i] == 1, p
+            continue
+        assert pr["status"][i] == 0, p
+        assert pr["frames"][i] == a.shape[0] and pr["channels"][i] == a.shape[1] and pr["rate"][i] == rate, p
+        want = {"s16": (1, 16), "u8": (1, 8), "f32": (3, 32)}[kind]
+        assert (pr["tag"][i], pr["bits"][i]) == want, p
+    ok = [i for i in range(len(paths)) if pr["status"][i] == 0 and pr["tag"][i] == 1 and pr["bits"][i] == 16 and pr["channels"][i] == 1]
+    assert [os.path.basename(paths[i]) for i in ok] == ["plain.wav", "list.wav", "ext.wav", "long.wav"]
+    lens = pr["frames"][ok]
+    offs = np.arange(len(ok), dtype=np.int64) * 1004
+    out = np.full(len(ok) * 1004, 77, np.int16)
+    st = N.wav_read_s16([paths[i] for i in ok], pr["data_off"][ok], lens, out, offs, threads=3)
+    assert (st == 0).all()
+    for k, i in enumerate(ok):
+        a, _, _ = wavio.read_wav_raw(paths[i])
+        assert np.array_equal(out[offs[k]: offs[k] + lens[k]], a[:, 0]), paths[i]
+        assert (out[offs[k] + lens[k]: offs[k] + 1004] == 77).all()          # nothing written past the clip
+    with pytest.raises(ValueError):
+        N.wav_read_s16([paths[ok[0]]], pr["data_off"][ok[:1]], lens[:1], out[:10], [0])
