@@ -8,8 +8,9 @@
 // SIMD (204 VGPRs, 78 KB of LDS per 4-wave workgroup, two workgroup barriers per 16 frames) and was measured at
 // ~86 % of that two-wave issue limit: it cannot get faster without more waves or fewer instructions.  This kernel
 // does both:
-//   * every wave is autonomous -- it owns a 16-frame block, walks it as 8 frame pairs, and never meets a
-//     workgroup barrier after the table set-up.  Per wave the LDS holds one 8.5 KB image that serves, in turn, the
+//   * every wave is autonomous -- it takes runs of 16-frame blocks (a contiguous share up front, then tickets:
+//     f3_runs_* in afx_frames3_dev.h), walks a block as 8 frame pairs, carries its rows from one block of a clip into
+//     the next, and never meets a workgroup barrier after the table set-up.  Per wave the LDS holds one 8.5 KB image that serves, in turn, the
 //     two FFT exchanges, the pair's power spectrum and the edge-row staging; 12 or 16 waves share one set of
 //     twiddle / mel tables (one workgroup per CU);
 //   * the butterflies are written as packed-f32 instructions with VOP3P op_sel / neg modifiers (inline asm): a
