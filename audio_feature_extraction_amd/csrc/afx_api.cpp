@@ -522,7 +522,11 @@ static int chunk_enqueue(afx_plan* pl, const void* samples, int fmt, int mem_kin
   pl->info_clean_n = 0;
   const bool want_stamps = dev_env().stamps;     // diagnostic build of k_frames
   const bool f3 = pl->use_f3 && !want_stamps && (!(kp.flags & 0x7f00) || dev_env().f3_debug);
-  const bool no_spec = dev_env().no_spec;       // A/B: the two-pass pipeline with k_frames3
+  bool no_spec = dev_env().no_spec;             // A/B: the two-pass pipeline with k_frames3
+  // k_trim_blocks sums 256-sample runs: it has the hop-sized sub-block sums the wave-level kernels' RMS rows need only
+  // for hops of 256 (or one sum per trim block); other shapes keep the speculative pipeline whatever the switch says
+  if (f3 && no_spec && kp.rms_sub > 1 && kp.trim_hop / kp.rms_sub != 256) no_spec = false;
+  if (!f3) kp.rms_sub = frames2_eligible(kp, pl->dt) ? kp.trim_hop / kp.hop : 0;      // round 1's kernels: their own rule
   if (f3 && !no_spec && pl->nblocks > 0) {
     // the samples are read once: frames before the trim decision (which the same pass feeds), then the few frames a cut touches
     const int max_items = n * kF3ItemsPerClip;
