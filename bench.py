@@ -12,16 +12,22 @@ decision, trim decision, redo launch, DCT, statistics; 4*n_mfcc+3 floats per cli
 Scaling is weak: every rank owns its own 1000 clips, no data-path collective; the only torch.distributed traffic is
 the timing barrier and the max-over-ranks reduction.  `python bench.py --gpus N` without a launcher starts the N ranks
 itself (children, before anything touches the GPU).
-Within a rank the clips are cut into --streams (default 3) runs that are in flight side by side, one context / HIP
-stream / host thread each -- how batch_process drives a GPU.  A step is still one pass over all of the rank's clips.
+Within a rank, by default two whole-batch steps are in flight (--inflight 2): two plans, each on its own stream
+(--queue own), driven from one host thread through afx_extract_submit / afx_extract_collect -- the frame kernels of
+consecutive steps run back to back, the small kernels of two steps side by side, and the host's share of a step falls
+under the other step's kernels.  --inflight 1 is one afx_extract_batch call at a time; --streams S > 1 is the older
+form (the clips cut into S runs, one context / stream / host thread each -- how batch_process drives a GPU).
+A step is always one pass over all of the rank's clips.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     -- the frame kernel (dominant): algorithmic bytes = 4*hop per frame (each input sample read once) /
                   average launch duration.  Durations come from HIP events recorded on the kernel's own stream around
                   every launch of the timed region; with several streams in flight the launches overlap, so the time
                   the GPU spends in the kernel is the UNION of their intervals (common device clock): avg_launch_ms =
-                  union / launches, and kernel time per step <= ms_per_step by construction.  `exclusive` is the same
-                  kernel over the whole batch on one stream (what profiles/r02_*_kernel_stats.csv shows);
+                  union / launches, and kernel time per step <= ms_per_step by construction (with two steps in flight
+                  on their own streams the second one's interval starts while the first still holds every CU, so the
+                  union contains the hand-over).  `exclusive` times every kernel of 20 calls made one at a time on a
+                  fresh context (what profiles/r02_*_kernel_stats.csv shows);
                   `fp32` the secondary vector-FLOP roofline (BASELINE.md 4);
   cpu_baseline -- the numpy/scipy oracle (a port of the reference's librosa path) timed on this box's host cores over a
                   bounded sample of the same workload: one core, and a pool over every core this process may use.
