@@ -28,7 +28,7 @@ SYMBOLS = (
     "afx_malloc", "afx_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
     "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables", "afx_build_mel_schedule",
     "afx_extract_batch", "afx_extract_submit", "afx_extract_collect", "afx_f0_batch", "afx_zcr_batch", "afx_spectral_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings", "afx_plan_get_intervals",
-    "afx_wav_probe", "afx_wav_read_s16",
+    "afx_wav_probe", "afx_wav_read_s16", "afx_batch_geometry",
 )
 
 
@@ -91,6 +91,7 @@ def lib() -> C.CDLL:
         L.afx_plan_set_timing.argtypes = [vp, i32]
         L.afx_plan_get_timings.argtypes = [vp, vp, vp, i32]
         L.afx_plan_get_intervals.argtypes = [vp, i32, vp, vp, i32, i32p]
+        L.afx_batch_geometry.argtypes = [C.POINTER(Params), vp, vp, i32, vp, vp]
         L.afx_wav_probe.argtypes = [vp, i32, i32, vp, vp, vp, vp]
         L.afx_wav_read_s16.argtypes = [vp, i32, i32, vp, vp, vp, C.c_int64, vp, vp]
         _lib = L
@@ -131,6 +132,20 @@ def wav_read_s16(paths, data_off, frames, out: np.ndarray, offsets, threads: int
         _check(lib().afx_wav_read_s16(arr, n, int(threads), data_off.ctypes.data, frames.ctypes.data, out.ctypes.data,
                                       int(out.size), offsets.ctypes.data, status.ctypes.data), "afx_wav_read_s16")
     return status
+
+
+def batch_geometry(p: "Params", offsets, lengths) -> dict:
+    """Host-only: how a ragged batch is laid out on the device (frame slots padded to 16-frame blocks)."""
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    lengths = np.ascontiguousarray(lengths, np.int64)
+    n = int(offsets.shape[0])
+    rec = np.zeros((max(n, 1), 4), np.int64)
+    tot = np.zeros(4, np.int64)
+    _check(lib().afx_batch_geometry(C.byref(p), offsets.ctypes.data, lengths.ctypes.data, n, rec.ctypes.data, tot.ctypes.data),
+           "afx_batch_geometry")
+    rec = rec[:n]
+    return {"frame_base": rec[:, 0], "tmax": rec[:, 1], "tpad": rec[:, 2], "blk_base": rec[:, 3],
+            "frame_slots": int(tot[0]), "blocks": int(tot[1]), "trim_blocks": int(tot[2]), "max_tmax": int(tot[3])}
 
 
 def f0_build_tables(sr: int, n_fft: int, hop: int, fmin: float, fmax: float) -> dict:

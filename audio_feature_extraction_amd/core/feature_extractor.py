@@ -193,34 +193,54 @@ class AudioFeatureExtractor:
         """提取能量特徵 of an already preprocessed signal (feature_extractor.py:153-179).  Only ``librosa.feature.rms``
         is involved there, so a clip with fewer than 9 frames -- which fails ``extract_mfcc`` on the width-9 delta --
         still has its energy statistics."""
+        return self._energy_from(y, 0)
+
+    def _energy_from(self, y: np.ndarray, flags: int) -> Dict[str, Any]:
         y = np.ascontiguousarray(y, dtype=np.float32)
-        out = self._plan().extract_batch(y, np.zeros(1, np.int64), np.array([y.size], np.int64), flags=0)
+        out = self._plan().extract_batch(y, np.zeros(1, np.int64), np.array([y.size], np.int64), flags=flags)
         st = int(out["status"][0])
-        rms_from_sums = 512 % self.hop_length == 0 and 512 // self.hop_length <= 4      # the kernels' sub-block RMS route
-        if st != _native.CLIP_OK and not (st == _native.CLIP_TOO_SHORT and y.size >= 2 and out["nframes"][0] >= 1 and rms_from_sums):
+        # a TOO_SHORT clip with at least two samples has its RMS statistics on every shape (include/afx.h, out_stats)
+        if st != _native.CLIP_OK and not (st == _native.CLIP_TOO_SHORT and y.size >= 2 and out["nframes"][0] >= 1):
             raise _status_error(st, "extract_energy", int(out["nframes"][0]))
         return self._stats_to_dicts(out["stats"][0])[1]
 
-    def extract_features(self, audio_path: str) -> Dict[str, Any]:
-        """提取所有特徵 (feature_extractor.py:181-213)."""
+    def extract_features(self, audio_path: str, *, features_to_extract: Optional[Sequence[str]] = None) -> Dict[str, Any]:
+        """提取所有特徵 (feature_extractor.py:181-213).
+
+        ``features_to_extract`` (keyword-only; README.md:141-146 shows ``['f0', 'mfcc', 'energy']``): the feature groups
+        wanted.  None = all three, the reference's behaviour; a subset leaves the other groups' keys out of the dict
+        (key order unchanged) and skips their GPU passes -- without ``'f0'`` no pYIN pass runs."""
         try:
+            from ..parallel import normalize_features
+            want = normalize_features(features_to_extract)
             y, _ = self.load_audio(audio_path)
+            f0_features: Dict[str, Any] = {}
+            mfcc_features: Dict[str, Any] = {}
+            energy_features: Dict[str, Any] = {}
             if self._uses_reference_stages():
-                # fused: pre-emphasis + trim + MFCC + RMS in one pass over the samples
-                stats = self._run_one(y, _native.FLAG_PREEMPH | _native.FLAG_TRIM)
-                f0_features = self._f0_to_dict(self._run_f0(y, _native.FLAG_PREEMPH | _native.FLAG_TRIM))
-                mfcc_features, energy_features = self._stats_to_dicts(stats)
+                flags = _native.FLAG_PREEMPH | _native.FLAG_TRIM
+                if "mfcc" in want:
+                    # fused: pre-emphasis + trim + MFCC + RMS in one pass over the samples
+                    mfcc_features, energy_features = self._stats_to_dicts(self._run_one(y, flags))
+                elif "energy" in want:
+                    energy_features = self._energy_from(y, flags)
+                if "f0" in want:
+                    f0_features = self._f0_to_dict(self._run_f0(y, flags))
             else:
                 y_processed = self.preprocess_audio(y)
-                f0_features = self.extract_f0(y_processed)
-                mfcc_features = self.extract_mfcc(y_processed)
-                energy_features = self.extract_energy(y_processed)
-            features = {
-                "file_path": audio_path,
-                **f0_features,
-                **mfcc_features,
-                **energy_features,
-            }
+                if "f0" in want:
+                    f0_features = self.extract_f0(y_processed)
+                if "mfcc" in want:
+                    mfcc_features = self.extract_mfcc(y_processed)
+                if "energy" in want:
+                    energy_features = self.extract_energy(y_processed)
+            features = {"file_path": audio_path}
+            if "f0" in want:
+                features.update(f0_features)
+            if "mfcc" in want:
+                features.update(mfcc_features)
+            if "energy" in want:
+                features.update(energy_features)
             return features
         except Exception as e:
             self.logger.error(f"特徵提取失敗: {str(e)}")
@@ -295,20 +315,22 @@ class AudioFeatureExtractor:
         """``np.savez(npz_path, **features)`` -- the reference's on-disk schema for frame-level features."""
         np.savez(npz_path, **features)
 
-    def batch_process(self, audio_dir: str) -> List[Dict[str, Any]]:
+    def batch_process(self, audio_dir: str, *, features_to_extract: Optional[Sequence[str]] = None) -> List[Dict[str, Any]]:
         """批量處理音頻文件 (feature_extractor.py:215-237): every ``*.wav`` directly inside
         ``audio_dir`` in glob order; a failing file is logged and left out.  Files are
-        sharded over the visible GPUs (no inter-GPU traffic; see parallel.py)."""
+        sharded over the visible GPUs (no inter-GPU traffic; see parallel.py).
+        ``features_to_extract``: as for ``extract_features``."""
+        from ..parallel import normalize_features, process_files
+        normalize_features(features_to_extract)            # a bad request fails the call, not every file
         files = list(Path(audio_dir).glob("*.wav"))
         if not self._uses_reference_stages():
             results = []
             for audio_file in files:
                 try:
-                    results.append(self.extract_features(str(audio_file)))
+                    results.append(self.extract_features(str(audio_file), features_to_extract=features_to_extract))
                     self.logger.info(f"成功處理文件: {audio_file.name}")
                 except Exception as e:
                     self.logger.error(f"處理文件 {audio_file.name} 失敗: {str(e)}")
                     continue
             return results
-        from ..parallel import process_files
-        return process_files(self, files)
+        return process_files(self, files, features_to_extract=features_to_extract)

@@ -14,14 +14,12 @@
 #include <hip/hip_runtime.h>
 
 #include "afx_device.h"
+#include "afx_devenv.h"
 #include "afx_f0.h"
 #include "afx_frames3.h"
 #include "afx_internal.h"
 
 namespace afx {
-
-static thread_local std::string g_err;
-void set_error(const std::string& s) { g_err = s; }
 
 struct DevBuf {
   void* p = nullptr;
@@ -49,7 +47,13 @@ struct afx_plan {
   std::vector<void*> table_allocs;
   DevBuf samples, clips, info, blocks, bsum, logmel, rms, mfcc, frames, frame_offs, stamps;     // statistics go straight to h_pin
   DevBuf blocks_spec, blockmax, items, n_items;      // speculative pipeline (k_frames3 before the trim decision)
-  std::vector<BlockDesc> h_blocks;
+  std::vector<BlockDesc> h_blocks;     // AFX_HOST_BLOCKS (A/B) only: the block list is built by k_build_blocks3
+  // pinned staging of the clip records: the upload is a true asynchronous copy, and the event tells when the
+  // staging may be rewritten (no stream synchronisation on a batch whose clip lengths are new)
+  ClipDesc* h_clips_pin = nullptr;
+  size_t h_clips_pin_cap = 0;
+  hipEvent_t clips_ev = nullptr;
+  bool clips_ev_pending = false;
   // extract_f0 (pYIN): tables for the last (fmin, fmax) used and the stage's workspace
   bool f0_ready = false;
   double f0_fmin = 0.0, f0_fmax = 0.0;
@@ -60,6 +64,7 @@ struct afx_plan {
   // cached per-batch descriptors
   std::vector<int64_t> c_off, c_len;
   std::vector<ClipDesc> h_clips;
+  std::vector<int64_t> h_rebased;   // per-frame output offsets of the pending chunk (source of an asynchronous upload: lives until collect)
   int nblocks = 0, max_tblocks = 0, max_tmax = 0;
   int64_t total_tpad = 0, total_tblk = 0;
   // pinned staging for the small per-call results (a device-to-pageable copy is staged and synchronous)
@@ -89,28 +94,30 @@ struct afx_plan {
   int n_cu = 256;
 };
 
-// Developer switches, read once per process (never on the per-call path): timing-only ablation bits for the frame
-// kernels, the per-phase stamp build of k_frames, the ablation build of k_frames3, and test-only chunk sizes that let
-// the multi-chunk paths be exercised with small batches.
-struct DevEnv {
-  int debug_skip = 0, f0_debug = 0;
-  bool stamps = false, f3_debug = false, no_spec = false, no_tickets = false;
-  int chunk_clips = 32768;
-  int64_t f0_chunk_frames = 1280 * 1024;
-  const char* f0_dump = nullptr;
-  DevEnv() {
-    if (const char* v = getenv("AFX_DEBUG_SKIP")) debug_skip = atoi(v) & 127;
-    if (const char* v = getenv("AFX_F0_DEBUG")) f0_debug = atoi(v);
-    stamps = getenv("AFX_DEBUG_STAMPS") != nullptr;
-    f3_debug = getenv("AFX_F3_DEBUG") != nullptr;
-    no_spec = getenv("AFX_NO_SPEC") != nullptr;
-    no_tickets = getenv("AFX_NO_TICKETS") != nullptr;      // A/B: equal static shares in the speculative frame launch
-    if (const char* v = getenv("AFX_TEST_CHUNK_CLIPS")) chunk_clips = std::max(1, std::min(32768, atoi(v)));
-    if (const char* v = getenv("AFX_TEST_F0_CHUNK_FRAMES")) f0_chunk_frames = std::max<int64_t>(64, atoll(v));
-    f0_dump = getenv("AFX_F0_DUMP");
-  }
-};
-static const DevEnv& dev_env() { static const DevEnv e; return e; }
+// Developer switches (afx_devenv.h): read once per process, never on the per-call path.
+namespace afx {
+DevEnv::DevEnv() {
+  if (const char* v = getenv("AFX_DEBUG_SKIP")) debug_skip = atoi(v) & 127;
+  if (const char* v = getenv("AFX_F0_DEBUG")) f0_debug = atoi(v);
+  stamps = getenv("AFX_DEBUG_STAMPS") != nullptr;
+  f3_debug = getenv("AFX_F3_DEBUG") != nullptr;
+  no_spec = getenv("AFX_NO_SPEC") != nullptr;
+  no_tickets = getenv("AFX_NO_TICKETS") != nullptr;      // A/B: equal static shares in the speculative frame launch
+  no_frames3 = getenv("AFX_NO_FRAMES3") != nullptr;
+  no_frames3s = getenv("AFX_NO_FRAMES3S") != nullptr;
+  no_frames3d = getenv("AFX_NO_FRAMES3D") != nullptr;
+  f3_generic_mel = getenv("AFX_F3_GENERIC_MEL") != nullptr;
+  generic_1024 = getenv("AFX_GENERIC_1024") != nullptr;
+  no_dct16l = getenv("AFX_NO_DCT16L") != nullptr;
+  host_blocks = getenv("AFX_HOST_BLOCKS") != nullptr;
+  no_fused_tail = getenv("AFX_NO_FUSED_TAIL") != nullptr;
+  if (const char* v = getenv("AFX_F3_WAVES")) f3_waves = atoi(v);
+  if (const char* v = getenv("AFX_TEST_CHUNK_CLIPS")) chunk_clips = std::max(1, std::min(32768, atoi(v)));
+  if (const char* v = getenv("AFX_TEST_F0_CHUNK_FRAMES")) f0_chunk_frames = std::max<int64_t>(64, atoll(v));
+  f0_dump = getenv("AFX_F0_DUMP");
+}
+const DevEnv& dev_env() { static const DevEnv e; return e; }
+}  // namespace afx
 
 #define HIP_TRY(expr)                                                                  \
   do {                                                                                 \
@@ -139,10 +146,6 @@ static void release(DevBuf& b) {
   if (b.p) (void)hipFree(b.p);
   b.p = nullptr; b.cap = 0;
 }
-
-extern "C" int afx_version(void) { return AFX_VERSION; }
-
-extern "C" const char* afx_last_error(void) { return g_err.c_str(); }
 
 extern "C" int afx_device_count(void) {
   int n = 0;
@@ -313,6 +316,8 @@ extern "C" void afx_plan_destroy(afx_plan* pl) {
   release(pl->frame_offs); release(pl->stamps);
   release(pl->blocks_spec); release(pl->blockmax); release(pl->items); release(pl->n_items);
   if (pl->h_pin) (void)hipHostFree(pl->h_pin);
+  if (pl->h_clips_pin) (void)hipHostFree(pl->h_clips_pin);
+  if (pl->clips_ev) (void)hipEventDestroy(pl->clips_ev);
   if (pl->done) (void)hipEventDestroy(pl->done);
   if (pl->flag) (void)hipHostFree((void*)pl->flag);
   if (pl->ev_ready)
@@ -384,58 +389,65 @@ static int prepare_descriptors(afx_plan* pl, const int64_t* offsets, const int64
   if (same) return AFX_OK;
   const int hop = pl->p.hop, th = pl->p.trim_hop;
   pl->h_clips.resize(n);
-  int64_t fb = 0, tb = 0;
-  int max_tb = 0, max_tm = 0;
-  int64_t nblk = 0;
-  for (int i = 0; i < n; ++i) {
-    if (lengths[i] < 0 || offsets[i] < 0) { set_error("negative clip offset/length"); return AFX_ERR_INVALID; }
-    if (lengths[i] / hop > (int64_t)1 << 30) { set_error("clip too long"); return AFX_ERR_INVALID; }
-    ClipDesc& c = pl->h_clips[i];
-    c.off = offsets[i]; c.len = lengths[i];
-    c.tmax = (int32_t)(1 + lengths[i] / hop);
-    c.tpad = (c.tmax + kFramesPerBlock - 1) / kFramesPerBlock * kFramesPerBlock;
-    c.frame_base = fb; c.tblk_base = tb;
-    fb += c.tpad;
-    const int64_t ntb = (lengths[i] + th - 1) / th;
-    tb += ntb;
-    max_tb = std::max<int>(max_tb, (int)ntb);
-    max_tm = std::max<int>(max_tm, c.tmax);
-    c.blk_base = (int32_t)nblk; c.pad_ = 0;
-    nblk += c.tpad / kFramesPerBlock;
-    if (nblk > (int64_t)1 << 30) { set_error("batch too large"); return AFX_ERR_INVALID; }
+  BatchGeom g;
+  {
+    std::string why;
+    if (!build_clip_descs(hop, th, offsets, lengths, n, pl->h_clips.data(), g, why)) { set_error(why); return AFX_ERR_INVALID; }
   }
-  pl->total_tpad = fb; pl->total_tblk = tb; pl->max_tblocks = std::max(max_tb, 1); pl->max_tmax = max_tm;
-  pl->nblocks = (int)nblk;
+  const int64_t nblk = g.nblocks;
+  pl->total_tpad = g.total_tpad; pl->total_tblk = g.total_tblk; pl->max_tblocks = g.max_tblocks; pl->max_tmax = g.max_tmax;
+  pl->nblocks = g.nblocks;
   int rc;
   if ((rc = ensure(pl->clips, n * sizeof(ClipDesc))) != AFX_OK) return rc;
   if ((rc = ensure(pl->blocks, std::max<size_t>((size_t)nblk, 1) * sizeof(BlockDesc))) != AFX_OK) return rc;
   hipStream_t s = pl->ctx->stream;
-  HIP_TRY(hipMemcpyAsync(pl->clips.p, pl->h_clips.data(), n * sizeof(ClipDesc), hipMemcpyHostToDevice, s));
+  // the clip records go through pinned staging of the plan's own: the previous upload from it has normally long
+  // completed (a plan has one batch in flight), the event only makes that certain
+  if (pl->clips_ev_pending) { HIP_TRY(hipEventSynchronize(pl->clips_ev)); pl->clips_ev_pending = false; }
+  if (pl->h_clips_pin_cap < (size_t)n) {
+    if (pl->h_clips_pin) (void)hipHostFree(pl->h_clips_pin);
+    pl->h_clips_pin = nullptr; pl->h_clips_pin_cap = 0;
+    const size_t want = (size_t)n + (size_t)n / 4 + 64;
+    HIP_TRY(hipHostMalloc((void**)&pl->h_clips_pin, want * sizeof(ClipDesc), hipHostMallocDefault));
+    pl->h_clips_pin_cap = want;
+  }
+  if (!pl->clips_ev) HIP_TRY(hipEventCreateWithFlags(&pl->clips_ev, hipEventDisableTiming));
+  std::memcpy(pl->h_clips_pin, pl->h_clips.data(), (size_t)n * sizeof(ClipDesc));
+  HIP_TRY(hipMemcpyAsync(pl->clips.p, pl->h_clips_pin, n * sizeof(ClipDesc), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipEventRecord(pl->clips_ev, s));
+  pl->clips_ev_pending = true;
   if (pl->use_f3) {
-    // the speculative pass's blocks: every absolute 16-frame block of every clip, nothing trimmed yet
-    const int per = pl->kp.rms_sub, half = pl->p.n_fft / 2;
-    const int64_t lim = (int64_t)1 << 30;
-    pl->h_blocks.resize((size_t)std::max<int64_t>(nblk, 1));
-    for (int i = 0; i < n; ++i) {
-      const ClipDesc& c = pl->h_clips[i];
-      const int64_t ntb = (c.len + th - 1) / th;
-      for (int b = 0; b < c.tpad / kFramesPerBlock; ++b) {
-        BlockDesc& d = pl->h_blocks[(size_t)c.blk_base + b];
-        const int64_t gs = (int64_t)b * kFramesPerBlock * hop - half;       // clip sample of staged index 0
-        auto rel = [&](int64_t x) { const int64_t q = x - gs; return (int32_t)(q < -lim ? -lim : (q > lim ? lim : q)); };
-        d.sample_base = c.off + gs; d.frame_slot = c.frame_base + (int64_t)b * kFramesPerBlock; d.clip_off = c.off;
-        d.keep_lo = rel(0); d.keep_hi = rel(c.len); d.have_lo = rel(0); d.have_hi = rel(c.len);
-        d.clip = i; d.t0 = b * kFramesPerBlock; d.T = c.tmax; d.active = (c.len >= 2 && d.t0 < c.tmax) ? 1 : 0;
-        d.pad_[0] = (int32_t)(c.tblk_base * per); d.pad_[1] = (int32_t)(ntb * per);
-      }
-    }
-    if ((rc = ensure(pl->blocks_spec, pl->h_blocks.size() * sizeof(BlockDesc))) != AFX_OK) return rc;
-    if ((rc = ensure(pl->blockmax, pl->h_blocks.size() * sizeof(float))) != AFX_OK) return rc;
+    // the speculative pass's blocks: every absolute 16-frame block of every clip, nothing trimmed yet -- written on the
+    // device from the clip records just uploaded (k_build_blocks3): a batch of new clip lengths costs the host one
+    // 48-byte record per clip, not a 64-byte record per 16 frames
+    const size_t nb_alloc = (size_t)std::max<int64_t>(nblk, 1);
+    if ((rc = ensure(pl->blocks_spec, nb_alloc * sizeof(BlockDesc))) != AFX_OK) return rc;
+    if ((rc = ensure(pl->blockmax, nb_alloc * sizeof(float))) != AFX_OK) return rc;
     if ((rc = ensure(pl->items, (size_t)n * kF3ItemsPerClip * sizeof(BlockDesc))) != AFX_OK) return rc;
     if ((rc = ensure(pl->n_items, 16)) != AFX_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(pl->blocks_spec.p, pl->h_blocks.data(), pl->h_blocks.size() * sizeof(BlockDesc), hipMemcpyHostToDevice, s));
+    if (!dev_env().host_blocks) {
+      HIP_TRY(launch_build_blocks3(s, (const ClipDesc*)pl->clips.p, n, (int)nblk, (BlockDesc*)pl->blocks_spec.p, pl->kp));
+    } else {                      // A/B: round 2's host-built list (3.5 MB for 1000 ten-second clips) and its synchronisation
+      const int per = pl->kp.rms_sub, half = pl->p.n_fft / 2;
+      const int64_t lim = (int64_t)1 << 30;
+      pl->h_blocks.resize(nb_alloc);
+      for (int i = 0; i < n; ++i) {
+        const ClipDesc& c = pl->h_clips[i];
+        const int64_t ntb = (c.len + th - 1) / th;
+        for (int b = 0; b < c.tpad / kFramesPerBlock; ++b) {
+          BlockDesc& d = pl->h_blocks[(size_t)c.blk_base + b];
+          const int64_t gs = (int64_t)b * kFramesPerBlock * hop - half;       // clip sample of staged index 0
+          auto rel = [&](int64_t x) { const int64_t q = x - gs; return (int32_t)(q < -lim ? -lim : (q > lim ? lim : q)); };
+          d.sample_base = c.off + gs; d.frame_slot = c.frame_base + (int64_t)b * kFramesPerBlock; d.clip_off = c.off;
+          d.keep_lo = rel(0); d.keep_hi = rel(c.len); d.have_lo = rel(0); d.have_hi = rel(c.len);
+          d.clip = i; d.t0 = b * kFramesPerBlock; d.T = c.tmax; d.active = (c.len >= 2 && d.t0 < c.tmax) ? 1 : 0;
+          d.pad_[0] = (int32_t)(c.tblk_base * per); d.pad_[1] = (int32_t)(ntb * per);
+        }
+      }
+      HIP_TRY(hipMemcpyAsync(pl->blocks_spec.p, pl->h_blocks.data(), pl->h_blocks.size() * sizeof(BlockDesc), hipMemcpyHostToDevice, s));
+      HIP_TRY(hipStreamSynchronize(s));   // h_blocks is pageable and rebuilt by the next call
+    }
   }
-  HIP_TRY(hipStreamSynchronize(s));   // h_clips may be rebuilt by the next call; descriptors change rarely
   pl->c_off.assign(offsets, offsets + n);
   pl->c_len.assign(lengths, lengths + n);
   return AFX_OK;
@@ -478,14 +490,16 @@ static int chunk_enqueue(afx_plan* pl, const void* samples, int fmt, int mem_kin
     if (pl->info.cap != before) pl->info_clean_n = 0;          // a new block: contents unknown
   }
   if ((rc = ensure(pl->bsum, std::max<int64_t>(pl->total_tblk, 1) * 4 * sizeof(float))) != AFX_OK) return rc;
-  if ((rc = ensure(pl->logmel, (size_t)pl->total_tpad * M * sizeof(float))) != AFX_OK) return rc;
+  // + 16 frames: with a left cut (frame offset start / hop > 0) the DCT's last 16-frame tile of the batch's last clip reads
+  // up to 15 rows past the clip's padded frame count (values discarded); they must be mapped memory
+  if ((rc = ensure(pl->logmel, (size_t)(pl->total_tpad + kFramesPerBlock) * M * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->rms, (size_t)pl->total_tpad * sizeof(float))) != AFX_OK) return rc;
   if ((rc = ensure(pl->mfcc, (size_t)pl->total_tpad * K * sizeof(float))) != AFX_OK) return rc;
   // Per-frame output: this chunk's clips occupy [f_lo, f_hi) of the caller's buffer.  The device copy holds exactly that
   // range (offsets rebased), so that a later chunk never touches -- or copies stale device memory over -- an earlier one's rows.
   float* d_frames = nullptr;
   int64_t f_lo = 0, f_hi = 0;
-  std::vector<int64_t> rebased;
+  std::vector<int64_t>& rebased = pl->h_rebased;
   if (out_frames) {
     if (!frame_offsets) { set_error("out_frames given without frame_offsets"); return AFX_ERR_INVALID; }
     f_lo = INT64_MAX;
@@ -540,7 +554,7 @@ static int chunk_enqueue(afx_plan* pl, const void* samples, int fmt, int mem_kin
     TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax, true, true));
   } else {
   TIMED(AFX_K_TRIM_BLOCKS, launch_trim_blocks(s, d_samples, d_clips, d_info, (float*)pl->bsum.p, n, pl->max_tblocks, kp));
-  TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, (float*)pl->rms.p, n, kp));
+  TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, (float*)pl->rms.p, n, kp, d_samples));
   if (pl->nblocks > 0) {
     const int grid = std::min(pl->nblocks, pl->n_cu * 2);
     unsigned long long* d_stamps = nullptr;
@@ -735,21 +749,6 @@ extern "C" int afx_extract_batch(afx_plan* pl, const void* samples, int sample_f
                            frame_offsets ? frame_offsets + c0 : nullptr);
     if (rc != AFX_OK) return rc;
   }
-  return AFX_OK;
-}
-
-extern "C" int afx_f0_build_tables(int sr, int n_fft, int hop, double fmin, double fmax, int32_t* info,
-                                   double* beta, double* lt, double* freqs) {
-  HostF0Tables t;
-  std::string why;
-  if (!build_f0_tables(sr, n_fft, hop, fmin, fmax, t, why)) { set_error("afx_f0_build_tables: " + why); return AFX_ERR_UNSUPPORTED; }
-  if (info) {
-    const int32_t v[8] = {t.p.min_period, t.p.max_period, t.p.n_bins, t.p.band, t.p.cap, t.p.n_lag, t.p.R, t.p.slots};
-    std::memcpy(info, v, sizeof(v));
-  }
-  if (beta) std::memcpy(beta, t.beta.data(), t.beta.size() * sizeof(double));
-  if (lt) std::memcpy(lt, t.lt.data(), t.lt.size() * sizeof(double));
-  if (freqs) std::memcpy(freqs, t.freqs.data(), t.freqs.size() * sizeof(double));
   return AFX_OK;
 }
 

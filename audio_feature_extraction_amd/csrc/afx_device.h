@@ -82,8 +82,11 @@ size_t frames_lds_bytes(int n_fft, int hop);
 
 hipError_t launch_trim_blocks(hipStream_t s, const void* samples, const ClipDesc* clips, ClipInfo* info,
                               float* bsum, int n_clips, int max_tblocks, const KParams& kp);
+// samples: the batch's packed samples when rms_rows is wanted (a clip of fewer than nine frames gets its RMS rows here
+// on the shapes whose frame kernel computes them); may be nullptr otherwise
 hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum,
-                              BlockDesc* blocks, float* rms_rows, int n_clips, const KParams& kp);
+                              BlockDesc* blocks, float* rms_rows, int n_clips, const KParams& kp,
+                              const void* samples = nullptr);
 // true when launch_frames will take the n_fft = 1024 / hop = 256 kernel (k_frames2) for this plan
 bool frames2_eligible(const KParams& kp, const DevTables& tb);
 hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,

@@ -80,6 +80,9 @@ hipError_t launch_spectral(hipStream_t s, const void* samples, ClipInfo* info, c
 hipError_t launch_frames3_any(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks, int nblocks,
                               const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
                               float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu);
+// the speculative launch's block list (every absolute 16-frame block of every clip) from the clip records, on the device
+hipError_t launch_build_blocks3(hipStream_t s, const ClipDesc* clips, int n_clips, int nblocks, BlockDesc* blocks,
+                                const KParams& kp);
 constexpr int kF3ItemsPerClip = 6;         // redo-list capacity per clip (k_trim_decide3)
 hipError_t launch_trim_decide3(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum, const float* blockmax,
                                BlockDesc* items, int* n_items, int max_items, float* rms_rows, int n_clips, const KParams& kp);

@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "afx_device.h"
+#include "afx_devenv.h"
 #include "afx_frames3.h"
 #include "afx_frames3_dev.h"
 
@@ -615,14 +616,52 @@ __global__ __launch_bounds__(256) void k_trim_decide3(const ClipDesc* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_build_blocks3: the speculative launch's block list, built on the device from the batch's clip records.
+// reference call site: audio_feature_extraction_toolkit/core/feature_extractor.py:228-235 -- batch_process never sees the
+// same clip lengths twice, so nothing per batch may be built block by block on the host: the host uploads one 48-byte
+// ClipDesc per clip and this kernel writes the 64-byte record of every absolute 16-frame block (one thread per block,
+// the clip found by bisection of blk_base).  54 000 records (3.5 MB) for 1000 ten-second clips.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_blocks3(const ClipDesc* __restrict__ clips, int n_clips, int nblocks,
+                                                       BlockDesc* __restrict__ blocks, int n_fft, int hop, int trim_hop, int per) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nblocks) return;
+  int lo = 0, hi = n_clips - 1;                   // last clip with blk_base <= g (clips without blocks cannot occur: tpad >= 16)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (clips[mid].blk_base <= g) lo = mid; else hi = mid - 1;
+  }
+  const ClipDesc c = clips[lo];
+  const int b = g - c.blk_base;
+  const int64_t lim = (int64_t)1 << 30;
+  const int64_t gs = (int64_t)b * kFramesPerBlock * hop - n_fft / 2;       // clip sample of staged index 0
+  auto rel = [&](int64_t x) { const int64_t q = x - gs; return (int32_t)(q < -lim ? -lim : (q > lim ? lim : q)); };
+  const int64_t ntb = (c.len + trim_hop - 1) / trim_hop;
+  BlockDesc d;
+  d.sample_base = c.off + gs; d.frame_slot = c.frame_base + (int64_t)b * kFramesPerBlock; d.clip_off = c.off;
+  d.keep_lo = rel(0); d.keep_hi = rel(c.len); d.have_lo = d.keep_lo; d.have_hi = d.keep_hi;
+  d.clip = lo; d.t0 = b * kFramesPerBlock; d.T = c.tmax; d.active = (c.len >= 2 && d.t0 < c.tmax) ? 1 : 0;
+  d.pad_[0] = (int32_t)(c.tblk_base * per); d.pad_[1] = (int32_t)(ntb * per);
+  blocks[g] = d;
+}
+
+hipError_t launch_build_blocks3(hipStream_t s, const ClipDesc* clips, int n_clips, int nblocks, BlockDesc* blocks,
+                                const KParams& kp) {
+  if (nblocks <= 0 || n_clips <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_build_blocks3, dim3((nblocks + 255) / 256), dim3(256), 0, s, clips, n_clips, nblocks, blocks,
+                     kp.n_fft, kp.hop, kp.trim_hop, kp.rms_sub);
+  return hipGetLastError();
+}
+
 bool frames3_eligible(const KParams& kp, const F3Tables& ft) {
   const int per = kp.hop > 0 ? kp.trim_hop / kp.hop : 0;
   if (!(ft.mel_rounds > 0 && kp.n_mels <= 512 && kp.hop > 0 && kp.trim_hop % kp.hop == 0 && per >= 1 && per <= 4) ||
-      getenv("AFX_NO_FRAMES3"))
+      dev_env().no_frames3)
     return false;
   if (kp.n_fft == 1024 && kp.hop == 256) return frames3_lds_bytes(12, ft) <= 160 * 1024;
-  if (kp.n_fft == 2048 && kp.hop == 512) return frames3s_lds_bytes(12, ft) <= 160 * 1024 && !getenv("AFX_NO_FRAMES3S");
-  if (kp.n_fft == 512 && kp.hop == 128) return frames3d_lds_bytes(12, ft) <= 160 * 1024 && !getenv("AFX_NO_FRAMES3D");
+  if (kp.n_fft == 2048 && kp.hop == 512) return frames3s_lds_bytes(12, ft) <= 160 * 1024 && !dev_env().no_frames3s;
+  if (kp.n_fft == 512 && kp.hop == 128) return frames3d_lds_bytes(12, ft) <= 160 * 1024 && !dev_env().no_frames3d;
   return false;
 }
 
@@ -635,7 +674,7 @@ hipError_t launch_frames3_any(hipStream_t s, const void* samples, ClipInfo* info
 }
 
 int frames3_waves(const F3Tables& ft) {
-  static const int forced = getenv("AFX_F3_WAVES") ? atoi(getenv("AFX_F3_WAVES")) : 0;
+  const int forced = dev_env().f3_waves;
   if (forced == 12 || forced == 16) return frames3_lds_bytes(forced, ft) <= 160 * 1024 ? forced : 12;
   return frames3_lds_bytes(16, ft) <= 160 * 1024 ? 16 : 12;
 }
@@ -666,7 +705,7 @@ static hipError_t launch_frames3_w(hipStream_t s, const void* samples, ClipInfo*
                                    float* logmel, float* blockmax, float* bsum, int* work_ctr, int n_cu) {
   // straight-line mel schedules compiled in: two rounds of width 1
   const bool two = ft.mel_rounds == 2 && ((ft.mel_rp[0] >> 4) & 15) == 1 && ((ft.mel_rp[1] >> 4) & 15) == 1 && ft.mel_all_own &&
-                   !getenv("AFX_F3_GENERIC_MEL");
+                   !dev_env().f3_generic_mel;
   const int nb0 = ft.mel_rp[0] & 15, nb1 = ft.mel_rp[1] & 15;
   if (two && nb0 == 2 && nb1 == 7)
     return launch_frames3_t<FMT, WAVES, 2, 7, SPEC>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu);

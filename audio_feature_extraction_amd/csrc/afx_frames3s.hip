@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "afx_device.h"
+#include "afx_devenv.h"
 #include "afx_frames3.h"
 #include "afx_frames3_dev.h"
 
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
 }
 
 int frames3s_waves(const F3Tables& ft) {
-  static const int forced = getenv("AFX_F3_WAVES") ? atoi(getenv("AFX_F3_WAVES")) : 0;
+  const int forced = dev_env().f3_waves;
   if (forced == 12 || forced == 16) return frames3s_lds_bytes(forced, ft) <= 160 * 1024 ? forced : 12;
   return frames3s_lds_bytes(16, ft) <= 160 * 1024 ? 16 : 12;
 }

@@ -66,4 +66,13 @@ void build_host_tables(const afx_params& p, HostTables& t);
 
 void set_error(const std::string& s);
 
+// afx_host.cpp: the clip records of a ragged batch (host-only; what prepare_descriptors uploads)
+struct ClipDesc;
+struct BatchGeom {
+  int64_t total_tpad = 0, total_tblk = 0;
+  int nblocks = 0, max_tblocks = 1, max_tmax = 0;
+};
+bool build_clip_descs(int hop, int trim_hop, const int64_t* offsets, const int64_t* lengths, int n, ClipDesc* out,
+                      BatchGeom& g, std::string& why);
+
 }  // namespace afx

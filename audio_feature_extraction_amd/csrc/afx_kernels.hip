@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "afx_device.h"
+#include "afx_devenv.h"
 #include "afx_f0.h"
 
 namespace afx {
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(256) void k_trim_decide(const ClipDesc* __restrict_
                                                      ClipInfo* __restrict__ info,
                                                      const float* __restrict__ bsum,
                                                      BlockDesc* __restrict__ blocks,
-                                                     float* __restrict__ rms_rows, KParams kp) {
+                                                     float* __restrict__ rms_rows, KParams kp,
+                                                     const void* __restrict__ samples) {
   __shared__ float red_f[4];
   __shared__ long long red_a[4], red_b[4];
   const int clip = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -320,6 +322,29 @@ __global__ __launch_bounds__(256) void k_trim_decide(const ClipDesc* __restrict_
         if (sb >= s_lo && sb < s_hi) sacc += bs[sb];
       }
       rms_rows[cd.frame_base + t] = sqrtf(sacc * inv_n);
+    }
+  }
+  // Shapes whose RMS rows come from the frame kernel (rms_sub == 0): a clip too short for the width-9 delta is skipped
+  // by that kernel (inactive blocks), but extract_energy only calls librosa.feature.rms (F:164) and must still get its
+  // statistics -- its fewer than nine frames are summed here, straight from the samples.
+  if (kp.rms_sub == 0 && rms_rows && samples && status == AFX_CLIP_TOO_SHORT && N >= 2 && T >= 1) {
+    const bool pre = (kp.flags & AFX_FLAG_PREEMPH) != 0;
+    const float inv_n = 1.0f / (float)kp.n_fft;
+    for (int t = wave; t < T; t += 4) {
+      float acc = 0.f;
+      for (int j = lane; j < kp.n_fft; j += 64) {
+        const int64_t i = start + (int64_t)t * kp.hop - kp.n_fft / 2 + j;
+        float v = 0.f;
+        if (i >= start && i < end) {
+          const float y = ld_sample(samples, kp.fmt, cd.off + i);
+          v = y;
+          if (pre) v = (i == 0) ? preemph0(y, ld_sample(samples, kp.fmt, cd.off + 1))
+                                : preemph1(y, ld_sample(samples, kp.fmt, cd.off + i - 1), kp.preemph_b1);
+        }
+        acc = fmaf(v, v, acc);
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) rms_rows[cd.frame_base + t] = sqrtf(acc * inv_n);
     }
   }
   // block descriptors of this clip for k_frames
@@ -1671,7 +1696,7 @@ __global__ __launch_bounds__(256) void k_stats(const ClipDesc* __restrict__ clip
   const ClipDesc cd = clips[clip];
   // a clip with fewer than 9 frames fails the MFCC rows (librosa.feature.delta raises) but still has an RMS row:
   // extract_energy (F:153-179) only calls librosa.feature.rms
-  const bool energy_only = ci.status == AFX_CLIP_TOO_SHORT && cd.len >= 2 && ci.T >= 1 && kp.rms_sub > 0;   // RMS rows from the sub-block sums
+  const bool energy_only = ci.status == AFX_CLIP_TOO_SHORT && cd.len >= 2 && ci.T >= 1;   // RMS rows from the sub-block sums, or from k_trim_decide
   if (ci.status != AFX_CLIP_OK && !(energy_only && row == K)) {
     if (lane == 0) {
       if (row < K) { st[row] = 0.f; st[K + row] = 0.f; st[2 * K + row] = 0.f; st[3 * K + row] = 0.f; }
@@ -1820,15 +1845,15 @@ hipError_t launch_trim_blocks(hipStream_t s, const void* samples, const ClipDesc
 }
 
 hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* info, const float* bsum,
-                              BlockDesc* blocks, float* rms_rows, int n_clips, const KParams& kp) {
-  hipLaunchKernelGGL(k_trim_decide, dim3(n_clips), dim3(256), 0, s, clips, info, bsum, blocks, rms_rows, kp);
+                              BlockDesc* blocks, float* rms_rows, int n_clips, const KParams& kp, const void* samples) {
+  hipLaunchKernelGGL(k_trim_decide, dim3(n_clips), dim3(256), 0, s, clips, info, bsum, blocks, rms_rows, kp, samples);
   return hipGetLastError();
 }
 
 bool frames2_eligible(const KParams& kp, const DevTables& tb) {
   const int per = kp.hop > 0 ? kp.trim_hop / kp.hop : 0;
   return kp.n_fft == 1024 && kp.hop == 256 && tb.mel_ntaps > 0 && frames2_lds_bytes(tb.mel_ntaps) <= 80 * 1024 && kp.n_mels <= 128 &&
-         kp.trim_hop % kp.hop == 0 && per >= 1 && per <= 4 && !getenv("AFX_GENERIC_1024");
+         kp.trim_hop % kp.hop == 0 && per >= 1 && per <= 4 && !dev_env().generic_1024;
 }
 
 template <int NFFT>
@@ -1984,7 +2009,7 @@ static hipError_t launch_dct_t(hipStream_t s, const ClipDesc* clips, const ClipI
       const int tiles = (max_tmax + 15) / 16;
       dim3 gl(std::max(1, (tiles + 63) / 64), n_clips);
       const size_t lds = (size_t)ncg * (kp.n_mels / 16) * 4 * 64 * sizeof(float);
-      if (getenv("AFX_NO_DCT16L")) {
+      if (dev_env().no_dct16l) {
         if (ncg == 2) hipLaunchKernelGGL((k_dct16<2, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
         else hipLaunchKernelGGL((k_dct16<3, FM>), g16, dim3(256), 0, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);
       } else if (ncg == 2) hipLaunchKernelGGL((k_dct16l<2, FM>), gl, dim3(256), lds, s, clips, info, tb.dctP, kp, logmel, mfcc, spec);

@@ -116,12 +116,12 @@ extern "C" int afx_wav_probe(const char* const* paths, int n, int threads, int32
 extern "C" int afx_wav_read_s16(const char* const* paths, int n, int threads, const int64_t* data_off,
                                 const int64_t* frames, int16_t* out, int64_t out_len, const int64_t* offsets,
                                 int32_t* status) {
-  if (n < 0 || (n > 0 && (!paths || !data_off || !frames || !out || !offsets || !status))) {
+  if (n < 0 || out_len < 0 || (n > 0 && (!paths || !data_off || !frames || !out || !offsets || !status))) {
     afx::set_error("afx_wav_read_s16: null/invalid argument");
     return AFX_ERR_INVALID;
   }
   for (int i = 0; i < n; ++i)
-    if (frames[i] < 0 || offsets[i] < 0 || offsets[i] + frames[i] > out_len) {
+    if (frames[i] < 0 || offsets[i] < 0 || frames[i] > out_len || offsets[i] > out_len - frames[i]) {      // no signed overflow
       afx::set_error("afx_wav_read_s16: a clip does not fit the output buffer");
       return AFX_ERR_INVALID;
     }

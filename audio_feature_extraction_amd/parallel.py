@@ -22,6 +22,7 @@ from typing import Any, Dict, List, Sequence, Tuple
 import numpy as np
 
 from . import _native, wavio
+from .hostinfo import usable_cpus
 
 
 def lpt_partition(lengths: Sequence[int], n_parts: int) -> List[List[int]]:
@@ -112,11 +113,34 @@ def _windows(sizes: Sequence[int], idxs: Sequence[int], budget: int) -> List[Lis
     return out
 
 
+FEATURE_GROUPS = ("f0", "mfcc", "energy")        # README.md:141-146 (features_to_extract); dict order is this order
+
+
+def normalize_features(features_to_extract) -> Tuple[str, ...]:
+    """None -> all three groups (the reference's behaviour); otherwise the requested subset, validated, in dict order."""
+    if features_to_extract is None:
+        return FEATURE_GROUPS
+    if isinstance(features_to_extract, str):
+        features_to_extract = [features_to_extract]
+    req = [str(f) for f in features_to_extract]
+    bad = [f for f in req if f not in FEATURE_GROUPS]
+    if bad:
+        raise ValueError(f"features_to_extract: unknown feature group(s) {bad}; choose from {list(FEATURE_GROUPS)}")
+    if not req:
+        raise ValueError(f"features_to_extract is empty; choose from {list(FEATURE_GROUPS)}")
+    return tuple(g for g in FEATURE_GROUPS if g in req)
+
+
 def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 1024 * 1024,
-                  workers_per_gpu: int = WORKERS_PER_GPU) -> List[Dict[str, Any]]:
+                  workers_per_gpu: int = WORKERS_PER_GPU, features_to_extract=None) -> List[Dict[str, Any]]:
     """Shard over GPUs (and over a few workers per GPU) -> per worker a pipeline of bounded windows:
     decode window k + 1 on the shared host pool while window k is packed, uploaded and extracted ->
     dicts in input (glob) order.  Host memory holds at most two windows per worker, not the directory.
+
+    On the device a worker owns two plans (own stream each): the MFCC / RMS pass of a sub-batch is queued with
+    afx_extract_submit on the first and collected only after the pYIN pass of the same sub-batch (afx_f0_batch, second
+    plan) has run beside it -- one upload serves both.  ``features_to_extract`` (README.md:141-146) leaves out the passes
+    nobody asked for: without 'f0' no pYIN pass runs (it is ~45x the MFCC pass).
 
     Error behaviour is the reference's (feature_extractor.py:229-235): a file that cannot be loaded, a clip the
     kernels reject, or a device-level failure while its window is processed is logged and left out; the batch goes on."""
@@ -134,6 +158,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
     nframes = np.zeros(n, np.int32)
     f0s = np.zeros((n, 4), np.float64)
     f0_done = np.zeros(n, bool)
+    nsamp = np.zeros(n, np.int64)
     lanes = [(d, w) for d in devices for w in range(max(1, int(workers_per_gpu)))]
     if n < 4 * len(lanes):                             # small jobs: one worker per GPU
         lanes = [(d, 0) for d in devices]
@@ -146,7 +171,10 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
     sizes = [fsize(f) for f in files]
     parts = lpt_partition(sizes, len(lanes))
     flags = _native.FLAG_PREEMPH | _native.FLAG_TRIM
-    pool = ThreadPoolExecutor(max(1, min(os.cpu_count() or 1, DECODE_THREADS_PER_GPU * len(devices), n)))
+    want = normalize_features(features_to_extract)
+    want_f0, want_stats = "f0" in want, ("mfcc" in want or "energy" in want)
+    host_cpus = usable_cpus()                   # the job's share of the host, not os.cpu_count()
+    pool = ThreadPoolExecutor(max(1, min(host_cpus, DECODE_THREADS_PER_GPU * len(devices), n)))
     phase = {"decode_wait": 0.0, "device": 0.0}
     phase_lock = threading.Lock()
 
@@ -162,7 +190,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
     # pass through Python: libafx parses their headers and reads their samples straight into the packed int16 batch
     # buffer with native threads (afx_wav_probe / afx_wav_read_s16).  Everything else, and any file the native reader
     # cannot open or parse, goes through wavio as before (which also produces the error a bad file is logged with).
-    native_threads = max(1, min(os.cpu_count() or 1, DECODE_THREADS_PER_GPU * len(devices)) // max(1, min(len(lanes), 4)))
+    native_threads = max(1, min(host_cpus, DECODE_THREADS_PER_GPU * len(devices)) // max(1, min(len(lanes), 4)))
     win_pool = ThreadPoolExecutor(max(1, len(lanes)))
 
     def load_window(win):
@@ -194,17 +222,32 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
         decoded = list(pool.map(dec, rest)) if rest else []
         return packed, rest, decoded
 
-    def run_group(plan, cur, buf, offs, lens, fmt):
+    def run_group(plans, cur, buf, offs, lens, fmt):
+        plan, plan_f0 = plans
         dbuf = plan.device_buffer(max(buf.nbytes, 16))            # one PCIe copy for both passes
         try:
             dbuf.upload(buf)
-            out = plan.extract_batch(dbuf, offs, lens, flags=flags, fmt=fmt)
-            f0 = plan.f0_batch(dbuf, offs, lens, extractor.f0_min, extractor.f0_max, flags=flags, fmt=fmt)
-            stats[cur] = out["stats"]
-            nframes[cur] = out["nframes"]
-            f0s[cur] = f0["stats"]
+            submitted = False
+            if want_stats:                                        # MFCC / RMS pass: queued, runs beside the pYIN pass below
+                plan.extract_submit(dbuf, offs, lens, flags=flags, fmt=fmt)
+                submitted = True
+            out = f0 = None
+            try:
+                if want_f0:
+                    f0 = plan_f0.f0_batch(dbuf, offs, lens, extractor.f0_min, extractor.f0_max, flags=flags, fmt=fmt)
+            finally:
+                if submitted:                                     # always: the buffer must outlive the queued pass
+                    out = plan.extract_collect()
+            nsamp[cur] = lens
+            if out is not None:
+                stats[cur] = out["stats"]
+                nframes[cur] = out["nframes"]
+            if f0 is not None:
+                f0s[cur] = f0["stats"]
             f0_done[cur] = True
-            status[cur] = out["status"]                           # last: a file counts only with both passes done
+            # last: a file counts only with every requested pass done.  Without the MFCC / RMS pass the f0 pass's own
+            # status (non-finite input) decides
+            status[cur] = out["status"] if out is not None else f0["status"]
         finally:
             dbuf.free()
 
@@ -219,8 +262,9 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
             pending = win_pool.submit(load_window, wins[k + 1]) if k + 1 < len(wins) else None
             t1 = time.perf_counter()
             try:
-                if plan is None:
-                    plan = extractor._plan(lane[0], lane[1])
+                if plan is None:                                  # (MFCC / RMS plan, pYIN plan): own context and stream each
+                    plan = (extractor._plan(lane[0], lane[1]),
+                            extractor._plan(lane[0], (lane[1], "f0")) if want_f0 else None)
                 if packed is not None:                            # the natively packed 16-bit clips, in budget-sized runs
                     ids, buf, offs, lens = packed
                     pos = 0
@@ -268,14 +312,23 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
     for i, f in enumerate(files):
         name = getattr(f, "name", str(f))
         err = errors[i]
-        if err is None and status[i] != _native.CLIP_OK:
+        # fewer than nine frames fails the MFCC group only (the width-9 delta); extract_energy has its statistics
+        energy_ok = ("mfcc" not in want and status[i] == _native.CLIP_TOO_SHORT and nsamp[i] >= 2 and nframes[i] >= 1)
+        if err is None and status[i] != _native.CLIP_OK and not energy_ok:
             err = _status_error(int(status[i]), "extract_features", int(nframes[i]))
             log.error(f"特徵提取失敗: {str(err)}")
         if err is not None:
             log.error(f"處理文件 {name} 失敗: {str(err)}")
             continue
         mfcc, energy = extractor._stats_to_dicts(stats[i])
-        results.append({"file_path": str(f), **extractor._f0_to_dict(f0s[i]), **mfcc, **energy})
+        rec: Dict[str, Any] = {"file_path": str(f)}
+        if want_f0:
+            rec.update(extractor._f0_to_dict(f0s[i]))
+        if "mfcc" in want:
+            rec.update(mfcc)
+        if "energy" in want:
+            rec.update(energy)
+        results.append(rec)
         log.info(f"成功處理文件: {name}")
     LAST_TIMING.update(pipeline=t_gpu - t_start, decode_wait=phase["decode_wait"], device=phase["device"],
                        dicts=time.perf_counter() - t_gpu, files=n, workers=len(threads))

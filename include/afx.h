@@ -122,6 +122,14 @@ int afx_build_tables(const afx_params* p, float* window, float* mel_dense, float
  * configuration has no such schedule. */
 int afx_build_mel_schedule(const afx_params* p, int32_t* info, float* weights, int32_t* meta);
 
+/* Host-only: the frame geometry of a ragged batch, as every batch entry point lays it out (batch_process hands over
+ * files of any length, F:228-235).  records[4 * n_clips]: per clip the first frame slot, Tmax = 1 + length / hop, Tmax
+ * padded to whole 16-frame blocks, first block index; totals[4]: frame slots, 16-frame blocks, trim blocks, largest
+ * Tmax.  Either pointer may be NULL.  AFX_ERR_INVALID for negative or oversized offsets / lengths (the same check the
+ * batch entry points make before anything is uploaded). */
+int afx_batch_geometry(const afx_params* p, const int64_t* offsets, const int64_t* lengths, int n_clips,
+                       int64_t* records, int64_t* totals);
+
 /* ---- the hot path ---------------------------------------------------------
  * One pass of preprocess_audio -> extract_mfcc + extract_energy (F:194,198,199)
  * over a ragged batch of clips.
@@ -134,6 +142,10 @@ int afx_build_mel_schedule(const afx_params* p, int32_t* info, float* weights, i
  *   out_stats host, n_clips * (4*n_mfcc + 3) floats per clip:
  *             mfcc_mean[K] mfcc_std[K] mfcc_delta_mean[K] mfcc_delta2_mean[K]
  *             energy_mean energy_std energy_range        (F:141-150, F:171-178)
+ *             A clip whose status is AFX_CLIP_TOO_SHORT because it has fewer than nine frames (the
+ *             width-9 delta of F:137 cannot be formed) but at least two samples still has its three
+ *             energy statistics, on every plan shape: extract_energy (F:153-179) only calls
+ *             librosa.feature.rms.  Its MFCC entries are zero.  Every other non-OK clip: all zero.
  *   out_status host int32[n_clips]  (afx_clip_status)
  *   out_trim  host int64[2*n_clips] (start, end) of the kept span, or NULL
  *   out_nframes host int32[n_clips] T = 1 + (end-start)/hop, or NULL
@@ -158,7 +170,11 @@ int afx_extract_batch(afx_plan* plan,
  * arrays given at submit (which, like `samples`, `offsets` and `lengths`, must stay valid until then).  Two plans of
  * one context submitted alternately from one thread run back to back on the device: the host's share of a batch
  * (collect, hand-out, next submit) falls under the other plan's kernels.  One batch per plan may be pending; n_clips
- * must be in [1, 32768]; afx_extract_batch(plan, ...) == submit + collect per 32768-clip chunk. */
+ * must be in [1, 32768]; afx_extract_batch(plan, ...) == submit + collect per 32768-clip chunk.
+ * A batch whose clip offsets / lengths differ from the plan's previous batch costs the host one 48-byte record per
+ * clip (pinned staging, asynchronous upload); the per-block work list is built on the device.  No stream
+ * synchronisation happens inside submit unless workspace has to grow.  With out_frames given, the copy of the
+ * per-frame matrices into the caller's (pageable) buffer is queued by submit and may make it block. */
 int afx_extract_submit(afx_plan* plan,
                        const void* samples, int sample_fmt, int mem_kind,
                        const int64_t* offsets, const int64_t* lengths, int n_clips,

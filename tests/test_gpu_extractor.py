@@ -203,3 +203,54 @@ def test_extract_energy_of_a_clip_too_short_for_the_delta():
             ex.extract_mfcc(y)
     with pytest.raises(ValueError):
         ex.extract_energy(np.array([0.3], np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frame_length,hop_length", [(2048, 256), (1024, 512), (256, 64), (512, 128), (2048, 512)])
+def test_extract_energy_of_a_too_short_clip_on_every_kernel_route(frame_length, hop_length):
+    """on shapes whose RMS rows come from the frame kernel (no sub-block sums: 2048/256, 1024/512,
+    256/64) a clip of fewer than nine frames used to come back with energy statistics of 0 that the class accepted.
+    Every route must return librosa.feature.rms's statistics (feature_extractor.py:164-178)."""
+    from oracle import cpu_ref as R
+    ex = AudioFeatureExtractor(frame_length=frame_length, hop_length=hop_length)
+    for frames in (1, 3, 6, 8):
+        n = hop_length * frames - hop_length // 3
+        y = make_clip(91 + frames, 22050, 0.5)[:n].copy()
+        assert 1 + n // hop_length == frames
+        e = ex.extract_energy(y)
+        ref = R.extract_energy(y, frame_length, hop_length)
+        assert float(ref["energy_mean"]) > 0.0
+        for k in ("energy_mean", "energy_std", "energy_range"):
+            assert type(e[k]) is float and abs(e[k] - float(ref[k])) <= 1e-5 * max(abs(float(ref[k])), 1e-3), (frames, k, e[k], ref[k])
+        with pytest.raises(ValueError):
+            ex.extract_mfcc(y)
+
+
+@pytest.mark.gpu
+def test_features_to_extract_subset_equals_the_full_dict_on_its_keys(tmp_path):
+    """README.md:141-146.  ['mfcc', 'energy'] skips the pYIN pass and must return, key for key, what the full call
+    returns; so must every other subset; a clip of fewer than nine frames fails only requests that include 'mfcc'."""
+    for i in range(5):
+        wavio.write_wav_pcm16(str(tmp_path / f"g{i}.wav"), make_clip(80 + i, 22050, 0.8 + 0.2 * i, speechy=bool(i % 2)), 22050)
+    wavio.write_wav_pcm16(str(tmp_path / "short.wav"), make_clip(60, 22050, 0.05), 22050)      # 5 frames < 9
+    ex = AudioFeatureExtractor()
+    full = {d["file_path"]: d for d in ex.batch_process(str(tmp_path))}
+    assert len(full) == 5
+    groups = {"f0": KEYS[1:5], "mfcc": KEYS[5:9], "energy": KEYS[9:]}
+    for subset in (["mfcc", "energy"], ["energy"], ["f0"], ["f0", "energy"], ["mfcc"]):
+        keys = ["file_path"] + [k for g in ("f0", "mfcc", "energy") if g in subset for k in groups[g]]
+        res = ex.batch_process(str(tmp_path), features_to_extract=subset)
+        assert len(res) == (5 if "mfcc" in subset else 6), (subset, len(res))
+        for d in res:
+            assert list(d) == keys
+            if d["file_path"] in full:
+                assert all(d[k] == full[d["file_path"]][k] for k in keys), subset
+            one = ex.extract_features(d["file_path"], features_to_extract=subset)
+            assert list(one) == keys
+            for k in keys[1:]:
+                a, b = np.asarray(one[k], np.float64), np.asarray(d[k], np.float64)
+                assert np.allclose(a, b, rtol=1e-6, atol=1e-9), (subset, k)
+    with pytest.raises(ValueError):
+        ex.extract_features(str(tmp_path / "short.wav"), features_to_extract=["mfcc", "energy"])
+    e = ex.extract_features(str(tmp_path / "short.wav"), features_to_extract=["energy"])
+    assert list(e) == ["file_path"] + KEYS[9:] and e["energy_mean"] > 0.0

@@ -90,3 +90,64 @@ def test_submit_and_collect_out_of_order_fail_cleanly():
         plan.extract_submit(buf, offs[:0], lens[:0])
     plan.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,n_fft,hop,n_mfcc", [(22050, 1024, 256, 13), (16000, 512, 128, 40), (44100, 2048, 512, 20)])
+def test_distinct_ragged_batches_through_two_plans(sr, n_fft, hop, n_mfcc):
+    """What bench.py --distinct times and batch_process does (feature_extractor.py:228-235: every window of files is
+    new): different ragged batches -- views of one device-resident buffer with other offsets and lengths each time --
+    alternated through two plans, so that every submit uploads new clip records and k_build_blocks3 rebuilds the block
+    list.  Batch for batch the results must equal those of a plan that has never seen another batch, and the oracle's."""
+    from tests.parity import check_stats, oracle_stats
+    rng = np.random.default_rng(5)
+    n = 24
+    clips = [make_clip(300 + i, sr, 0.5 + 0.07 * (i % 5), speechy=(i % 4 == 0)) for i in range(n)]
+    lens = np.array([c.size for c in clips], np.int64)
+    offs = np.zeros(n, np.int64)
+    offs[1:] = np.cumsum((lens + 3) // 4 * 4)[:-1]
+    buf = np.zeros(int(offs[-1] + lens[-1]), np.float32)
+    for c, o in zip(clips, offs):
+        buf[o:o + c.size] = c
+    ctx = N.Context(0)
+    dbuf = N.DeviceBuffer(ctx, buf.nbytes)
+    dbuf.upload(buf)
+    variants = []
+    for j in range(5):
+        a = rng.integers(0, 3000, n).astype(np.int64)
+        b = rng.integers(0, 3000, n).astype(np.int64)
+        keep = rng.permutation(n)[: n - 3 * j]                      # another clip count per batch, too
+        keep.sort()
+        variants.append((np.ascontiguousarray((offs + a)[keep]), np.ascontiguousarray((lens - a - b)[keep])))
+    params = lambda: N.make_params(sr, n_fft, hop, n_mfcc)   # noqa: E731
+    want = []
+    for vo, vl in variants:
+        fresh = N.Plan(ctx, params())
+        want.append(fresh.extract_batch(dbuf, vo, vl))
+        fresh.close()
+    plans = [N.Plan(ctx, params()) for _ in range(2)]
+    held = [None, None]
+    got = {}
+    order = [0, 1, 2, 3, 4, 2, 0, 4, 1, 3, 3, 0]                    # every variant through both plans, one repeat in a row
+    for step, v in enumerate(order):
+        p = step % 2
+        if held[p] is not None:
+            got.setdefault(held[p][1], []).append(plans[p].extract_collect())
+        plans[p].extract_submit(dbuf, *variants[v])
+        held[p] = (step, v)
+    for p in (0, 1):
+        if held[p] is not None:
+            got.setdefault(held[p][1], []).append(plans[p].extract_collect())
+    for v, outs in got.items():
+        for o in outs:
+            _same(o, want[v])
+    # and the values themselves, against the oracle, for one variant
+    vo, vl = variants[1]
+    for i in range(0, len(vo), 5):
+        if want[1]["status"][i] == 0:
+            y = buf[vo[i]: vo[i] + vl[i]]
+            check_stats(want[1]["stats"][i], oracle_stats(y, sr, n_fft, hop, n_mfcc), n_mfcc, f"variant 1 clip {i}")
+    dbuf.free()
+    for p in plans:
+        p.close()
+    ctx.close()

@@ -28,5 +28,13 @@ for win in wins:
     print(f"batch_process: {len(out)} files of {dur:.0f} s in {dt*1e3:.0f} ms = {len(out)/dt:.0f} files/s, "
           f"{frames/dt/1e6:.2f} Mframes/s end to end (decode + MFCC/RMS + pYIN), host cpus {os.cpu_count()}")
     print("  phases (s):", {k: round(v, 4) for k, v in parallel.LAST_TIMING.items()})
+# features_to_extract (README.md:141-146): the same directory without the pYIN pass
+for rep in range(2):
+    t0 = time.perf_counter()
+    out = ex.batch_process(d, features_to_extract=["mfcc", "energy"])
+    dt = time.perf_counter() - t0
+    print(f"batch_process(features_to_extract=['mfcc', 'energy']): {len(out)} files in {dt*1e3:.0f} ms = {len(out)/dt:.0f} files/s "
+          f"(decode + MFCC/RMS, no pYIN)")
+    print("  phases (s):", {k: round(v, 4) for k, v in parallel.LAST_TIMING.items()})
 for f in os.listdir(d): os.remove(os.path.join(d, f))
 os.rmdir(d)
