@@ -541,6 +541,10 @@ static int chunk_enqueue(afx_plan* pl, const void* samples, int fmt, int mem_kin
   // for hops of 256 (or one sum per trim block); other shapes keep the speculative pipeline whatever the switch says
   if (f3 && no_spec && kp.rms_sub > 1 && kp.trim_hop / kp.rms_sub != 256) no_spec = false;
   if (!f3) kp.rms_sub = frames2_eligible(kp, pl->dt) ? kp.trim_hop / kp.hop : 0;      // round 1's kernels: their own rule
+  // No per-frame output wanted: one kernel per clip does clamp + DCT + statistics and the MFCC rows stay on the chip
+  // (k_tail).  A batch of very few, very long clips keeps the many-workgroups-per-clip kernels.
+  const bool fused_tail = f3 && pl->nblocks > 0 && !out_frames && !dev_env().no_fused_tail && tail_eligible(kp, pl->dt) &&
+                          (n >= 32 || pl->max_tmax <= 2048);
   if (f3 && !no_spec && pl->nblocks > 0) {
     // the samples are read once: frames before the trim decision (which the same pass feeds), then the few frames a cut touches
     const int max_items = n * kF3ItemsPerClip;
@@ -551,7 +555,8 @@ static int chunk_enqueue(afx_plan* pl, const void* samples, int fmt, int mem_kin
                                                  (BlockDesc*)pl->items.p, (int*)pl->n_items.p, max_items, (float*)pl->rms.p, n, kp));
     TIMED(AFX_K_TRIM_BLOCKS, launch_frames3_any(s, d_samples, d_info, (const BlockDesc*)pl->items.p, max_items, (const int*)pl->n_items.p,
                                             pl->f3, kp, (float*)pl->logmel.p, nullptr, nullptr, false, nullptr, pl->n_cu));
-    TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax, true, true));
+    if (!fused_tail)
+      TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax, true, true));
   } else {
   TIMED(AFX_K_TRIM_BLOCKS, launch_trim_blocks(s, d_samples, d_clips, d_info, (float*)pl->bsum.p, n, pl->max_tblocks, kp));
   TIMED(AFX_K_TRIM_DECIDE, launch_trim_decide(s, d_clips, d_info, (const float*)pl->bsum.p, (BlockDesc*)pl->blocks.p, (float*)pl->rms.p, n, kp, d_samples));
@@ -592,9 +597,11 @@ static int chunk_enqueue(afx_plan* pl, const void* samples, int fmt, int mem_kin
         fprintf(stderr, "\n");
       }
     }
-    TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax, f3));
+    if (!fused_tail)
+      TIMED(AFX_K_DCT, launch_dct(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (float*)pl->mfcc.p, n, pl->max_tmax, f3));
   }
   }
+  const int tail_spec = (f3 && !no_spec) ? 1 : 0;          // the spill holds absolute frames (speculative pipeline)
   // The batch's small results (statistics, clip records) are written by k_stats straight into pinned host memory the
   // device can address: no copy commands behind the last kernel (each cost ~15 us of stream time).
   const size_t stats_bytes = (size_t)n * nstat * sizeof(float), info_bytes = (size_t)n * sizeof(ClipInfo);
@@ -608,6 +615,10 @@ static int chunk_enqueue(afx_plan* pl, const void* samples, int fmt, int mem_kin
     pl->h_pin_cap = want;
   }
   const size_t info_at = (stats_bytes + 15) & ~(size_t)15;
+  if (fused_tail)
+    TIMED(AFX_K_DCT, launch_tail(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (const float*)pl->rms.p,
+                                 (float*)pl->h_pin_dev, (ClipInfo*)((char*)pl->h_pin_dev + info_at), n, tail_spec));
+  else
   TIMED(AFX_K_STATS, launch_stats(s, d_clips, d_info, kp, (const float*)pl->mfcc.p, (const float*)pl->rms.p,
                                   (float*)pl->h_pin_dev, d_frames, (const int64_t*)pl->frame_offs.p, n,
                                   (ClipInfo*)((char*)pl->h_pin_dev + info_at)));

@@ -102,5 +102,10 @@ hipError_t launch_stats(hipStream_t s, const ClipDesc* clips, const ClipInfo* in
                         const float* mfcc, const float* rms_rows, float* stats, float* frames_out,
                         const int64_t* frame_offsets, int n_clips, ClipInfo* info_out = nullptr);
 hipError_t launch_preemph(hipStream_t s, const float* y, float* out, int64_t n, float b1);
+// afx_tail.hip: clamp + DCT + statistics of a clip in one workgroup, from the frame-major log-mel spill of the wave-level
+// frame kernels; the MFCC rows are never written.  Replaces launch_dct + launch_stats when no per-frame output is wanted.
+bool tail_eligible(const KParams& kp, const DevTables& tb);
+hipError_t launch_tail(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb, const KParams& kp,
+                       const float* logmel, const float* rms_rows, float* stats, ClipInfo* info_out, int n_clips, int spec);
 
 }  // namespace afx

@@ -41,6 +41,10 @@
 #include "afx_frames3.h"
 #include "afx_frames3_dev.h"
 
+#ifndef F3_EXP
+#define F3_EXP 0          // experiment bits (same-box A/B builds only; the shipped value is what the A/B left standing)
+#endif
+
 namespace afx {
 
 size_t frames3_lds_bytes(int waves, const F3Tables& ft) {
@@ -87,9 +91,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
   const unsigned long long stamp0 = wall_clock64();
 #endif
   float* const tabs = smem + WAVES * kF3ExFloats;
-  v2* const T2 = reinterpret_cast<v2*>(tabs);                 // [r][16]: W_128^(c r)
-  v2* const T3a = reinterpret_cast<v2*>(tabs + 256);          // [r-1][lane]: W_1024^(ja r)
-  v2* const T3b = reinterpret_cast<v2*>(tabs + 256 + 896);    // [r-1][lane]: W_1024^(jb r)
+  // twiddles as 16-byte entries, one LDS read for two: an LDS instruction costs the SIMD ~8 cycles of issue whatever its width
+  float4* const T2q = reinterpret_cast<float4*>(tabs);        // [rr][16]: (W_128^(c 2rr), W_128^(c (2rr + 1))), rr < 4
+  float4* const T3q = reinterpret_cast<float4*>(tabs + 256);  // [r-1][lane]: (W_1024^(ja r), W_1024^(jb r))
   float* const MW = tabs + kF3TabFloats;                      // mel weights [round][batch][lane][4]
   int* const MM = reinterpret_cast<int*>(MW + ft.mel_wfloats);   // mel meta [round][lane]
   v2* const E = reinterpret_cast<v2*>(smem + wave * kF3ExFloats);
@@ -99,29 +103,28 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
   {
     const v2* w1024 = reinterpret_cast<const v2*>(ft.w1024);
     auto W = [&](int m) { const v2 v = w1024[m & 511]; return (m & 512) ? -v : v; };
-    if (tid < 128) T2[tid] = W(8 * (tid >> 4) * (tid & 15));
     if (tid < 64) {
+      const int rr = tid >> 4, c = tid & 15;
+      const v2 a = W(8 * (2 * rr) * c), b = W(8 * (2 * rr + 1) * c);
+      T2q[tid] = float4{a.x, a.y, b.x, b.y};
       const int jbt = tid ? 128 - tid : 64;
 #pragma unroll
-      for (int r = 1; r < 8; ++r) { T3a[(r - 1) * 64 + tid] = W(tid * r); T3b[(r - 1) * 64 + tid] = W(jbt * r); }
+      for (int r = 1; r < 8; ++r) { const v2 ta = W(tid * r), tb = W(jbt * r); T3q[(r - 1) * 64 + tid] = float4{ta.x, ta.y, tb.x, tb.y}; }
     }
     for (int i = tid; i < ft.mel_wfloats; i += WAVES * 64) MW[i] = ft.mel_w[i];
     for (int i = tid; i < ft.mel_rounds * 64; i += WAVES * 64) MM[i] = ft.mel_meta[i];
     for (int i = lane; i < kF3ExFloats; i += 64) XB[i] = 0.f;
   }
-  // the lane's 16 window values (w[n] = w[N - n]) x 0.5 as a 4 KB table [u / 2][lane] of pairs, read back per frame pair:
-  // 16 registers less, so that the kernel fits 128 registers at 16 waves per CU and, at 12 waves, leaves the other
-  // streams' bandwidth-bound kernels (DCT 74 registers, statistics 56) room to run beside it on the same SIMDs
-  constexpr bool WLDS = true;
-  v2* const WT = reinterpret_cast<v2*>(MM + ft.mel_rounds * 64);
-  float wreg[16];
+  // the lane's 16 window values (w[n] = w[N - n]) x 0.5 as a 4 KB table [u / 4][lane] of quadruples, read back per frame
+  // pair (four 16-byte reads): 16 registers less, so that the kernel fits 128 registers at 16 waves per CU and, at 12
+  // waves, leaves the other streams' bandwidth-bound kernels (DCT 74 registers, statistics 56) room beside it
+  float4* const WT = reinterpret_cast<float4*>(MM + ft.mel_rounds * 64);
+  if (tid < 64) {
+    float wreg[16];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) wreg[u] = 0.5f * ft.window[u < 8 ? lane + 64 * u : (64 - lane) + 64 * (15 - u)];
-  if constexpr (WLDS) {
-    if (tid < 64) {
+    for (int u = 0; u < 16; ++u) wreg[u] = 0.5f * ft.window[u < 8 ? lane + 64 * u : (64 - lane) + 64 * (15 - u)];
 #pragma unroll
-      for (int v = 0; v < 8; ++v) WT[v * 64 + lane] = v2{wreg[2 * v], wreg[2 * v + 1]};
-    }
+    for (int v = 0; v < 4; ++v) WT[v * 64 + lane] = float4{wreg[4 * v], wreg[4 * v + 1], wreg[4 * v + 2], wreg[4 * v + 3]};
   }
   __syncthreads();
   const v2 H = {0.70710678118654752440f, 0.70710678118654752440f};
@@ -190,7 +193,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     BlockDesc bd = blocks[b];
     if (!bd.active) continue;
     bool first = true;                                    // first block of a run: its 20 rows are loaded; later ones inherit them
-    v2 R[16];
+    // Rows live as pairs R[u] = (row u, row u + 4): exactly the (frame A, frame B) operands of z[u], so the window multiply
+    // is one packed instruction per point.  Ra = R[0..7], Rb = R[8..15]; a pair's successor shares rows 8..19, so its
+    // R'[0..7] ARE Rb: the two arrays swap roles from pair to pair (the loop body below is written once and instantiated
+    // for both roles) instead of being copied -- 16 register moves per pair less.
+    v2 Ra[8], Rb[8];
     for (;;) {                                            // the blocks of one run
     const int Tleft = bd.T - bd.t0;                       // frames left from this block on (>= 1)
     const int npairs = Tleft >= 16 ? 8 : (Tleft + 1) >> 1;
@@ -217,8 +224,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       return (j >= bd.keep_lo && j < bd.keep_hi) ? v : 0.f;
     };
 
-    // ---- rows of the first pair: staged samples [0, 1280).  Rows live as pairs R[u] = (row u, row u + 4): exactly the
-    // (frame A, frame B) operands of z[u], so the window multiply is one packed instruction per point.
+    // ---- rows of the first pair: staged samples [0, 1280)
     if (first) {
       float rows[20];
       if (interior(0, N + HOP)) {
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         for (int u = 0; u < 20; ++u) rows[u] = XB[64 * u + lane];
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) R[u] = v2{rows[u], rows[u + 4]};
+      for (int u = 0; u < 8; ++u) { Ra[u] = v2{rows[u], rows[u + 4]}; Rb[u] = v2{rows[u + 8], rows[u + 12]}; }
       if constexpr (SPEC) {
         // rows 8..11 / 12..15 / 16..19 are sub-blocks t0, t0 + 1, t0 + 2 of the clip; the first belongs to the
         // previous block's last pair unless this is the clip's first block
@@ -248,26 +254,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     float* const tile = logmel + bd.frame_slot * (int64_t)M;     // [frame][mel]
     const bool blk_int = interior(0, 512 * 8 + 768 + 512);       // every row this block (and a chained successor's first pair) loads
 
-#pragma unroll 1
-    for (int p = 0; p < npairs; ++p) {
+    // One frame pair.  P = R[0..7], Q = R[8..15] of this pair; on return Q, P (in that order) are the next pair's rows.
+    auto pair_body = [&](v2 (&P)[8], v2 (&Q)[8], const int p) __attribute__((always_inline)) {
       // ---- z = w yA + i w yB (frame A: rows 0..15, frame B: rows 4..19)
       v2 z[16];
-      if constexpr (WLDS) {
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
-          const v2 w = ldv(WT + v * 64 + lane);
-          z[2 * v] = R[2 * v] * v2{w.x, w.x}; z[2 * v + 1] = R[2 * v + 1] * v2{w.y, w.y};
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) z[u] = R[u] * v2{wreg[u], wreg[u]};
+      for (int v = 0; v < 4; ++v) {
+        const float4 w = ldv4(WT + v * 64 + lane);
+        const v2* const src = v < 2 ? P + 4 * v : Q + 4 * (v - 2);
+        z[4 * v] = src[0] * v2{w.x, w.x}; z[4 * v + 1] = src[1] * v2{w.y, w.y};
+        z[4 * v + 2] = src[2] * v2{w.z, w.z}; z[4 * v + 3] = src[3] * v2{w.w, w.w};
       }
-      // the next pair shares rows 8..19 and brings 8 new ones, n[0..7] = rows 20..27 of this pair's window:
-      //   R'[u] = R[u + 8] (u < 8),  R'[8 + i] = (R[12 + i].y, n[i]),  R'[12 + i] = (n[i], n[4 + i])
+      // the next pair shares rows 8..19 (Q) and brings 8 new ones, n[0..7] = rows 20..27 of this pair's window; they go
+      // where P is (dead from here on):  P'[i] = (Q[4 + i].y, n[i]),  P'[4 + i] = (n[i], n[4 + i])
 #pragma unroll
-      for (int u = 0; u < 8; ++u) R[u] = R[u + 8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) R[8 + i].x = R[12 + i].y;
+      for (int i = 0; i < 4; ++i) P[i].x = Q[4 + i].y;
       const bool more = p + 1 < npairs || chain;           // the next pair may be the next block's first
       const int jn = 512 * (p + 1) + 768;                  // staged samples [jn, jn + 512)
       const bool nint = more && (blk_int || interior(jn, jn + 512));
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       f3_dft16(z, H, W1, W3);
       if (!F3_SKIP(0x200)) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) e1w[k] = z[k];
+      for (int k = 0; k < 16; ++k) { if constexpr ((F3_EXP & 1) != 0) stv(e1w + k, z[k]); else e1w[k] = z[k]; }
 #pragma unroll
       for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 68 * u);
       }
@@ -284,7 +285,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       {
         v2 tw[8];
 #pragma unroll
-        for (int r = 1; r < 8; ++r) tw[r] = ldv(T2 + r * 16 + (lane & 15));
+        for (int rr = 0; rr < 4; ++rr) {
+          const float4 t = ldv4(T2q + rr * 16 + (lane & 15));
+          tw[2 * rr] = v2{t.x, t.y}; tw[2 * rr + 1] = v2{t.z, t.w};
+        }
         v2 xa[8], xb[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) { xa[r] = z[2 * r]; xb[r] = z[2 * r + 1]; }
@@ -293,7 +297,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         f3_dft8(xa, H); f3_dft8(xb, H);
         if (!F3_SKIP(0x2000)) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { e2w[16 * r] = xa[r]; e2w[16 * r + 512] = xb[r]; }
+        for (int r = 0; r < 8; ++r) {
+          if constexpr ((F3_EXP & 2) != 0) { stv(e2w + 16 * r, xa[r]); stv(e2w + 16 * r + 512, xb[r]); }
+          else { e2w[16 * r] = xa[r]; e2w[16 * r + 512] = xb[r]; }
+        }
         } else {
 #pragma unroll
           for (int r = 0; r < 8; ++r) { z[2 * r] = xa[r]; z[2 * r + 1] = xb[r]; }
@@ -309,7 +316,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         for (int r = 0; r < 8; ++r) { A[r] = z[r]; B[r] = z[r + 8]; }
       }
 #pragma unroll
-      for (int r = 1; r < 8; ++r) cmul2(A[r], ldv(T3a + (r - 1) * 64 + lane), B[r], ldv(T3b + (r - 1) * 64 + lane));
+      for (int r = 1; r < 8; ++r) {
+        const float4 t = ldv4(T3q + (r - 1) * 64 + lane);
+        cmul2(A[r], v2{t.x, t.y}, B[r], v2{t.z, t.w});
+      }
       f3_dft8(A, H); f3_dft8(B, H);
       // A[s] = Z[lane + 128 s], B[s] = Z[jb + 128 s]; the mirror of A[s] is B[7-s].  Lane 0 owns the self-mirrored
       // butterflies 0 and 64: its pairs are (A[s], A[8-s]) and (B[s], B[7-s]) -- re-seat its registers once so
@@ -322,13 +332,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       for (int s = 0; s < 4; s += 2) {
         v2 p0, p1;
         sqsum2(A[s] + B[7 - s], A[s] - B[7 - s], A[s + 1] + B[6 - s], A[s + 1] - B[6 - s], p0, p1);
-        ea[128 * s] = p0; ea[128 * (s + 1)] = p1;
+        if constexpr ((F3_EXP & 4) != 0) { stv(ea + 128 * s, p0); stv(ea + 128 * (s + 1), p1); } else { ea[128 * s] = p0; ea[128 * (s + 1)] = p1; }
       }
 #pragma unroll
       for (int s = 4; s < 8; s += 2) {
         v2 p0, p1;
         sqsum2(A[s] + B[7 - s], A[s] - B[7 - s], A[s + 1] + B[6 - s], A[s + 1] - B[6 - s], p0, p1);
-        eb[384 - 128 * (s - 4)] = p0; eb[384 - 128 * (s - 3)] = p1;
+        if constexpr ((F3_EXP & 4) != 0) { stv(eb + 384 - 128 * (s - 4), p0); stv(eb + 384 - 128 * (s - 3), p1); } else { eb[384 - 128 * (s - 4)] = p0; eb[384 - 128 * (s - 3)] = p1; }
       }
       if (lane == 0) E[512] = v2{4.f * nyq.x * nyq.x, 4.f * nyq.y * nyq.y};
       } else {
@@ -344,6 +354,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         for (int u = 0; u < 8; ++u) { ny[u] = row_ld(sp + jn, 64 * u + lane); nyp[u] = row_ld(sp + jn - 1, 64 * u + lane); }
       }
       // ---- mel + dB
+      if constexpr ((F3_EXP & 8) != 0) __builtin_amdgcn_s_setprio(1);
+      if constexpr ((F3_EXP & 16) != 0) __builtin_amdgcn_s_setprio(0);
       const bool vA = 2 * p < Tleft, vB = 2 * p + 1 < Tleft;
       float* const rowA = tile + (unsigned)(2 * p * M);
       if constexpr (NB0 > 0) {
@@ -352,18 +364,32 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         const float4* pp1 = reinterpret_cast<const float4*>(E + (meta1 & 2047));
         const float4* ww0 = reinterpret_cast<const float4*>(MW) + lane;
         const float4* ww1 = reinterpret_cast<const float4*>(MW + NB0 * 256) + lane;
-        v2 s0[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, s1[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        // (A, B) bin pairs times a weight taken from either half of a register pair: the half is an op_sel modifier
+        // (f3_mel_*), not a move (hipcc's own code for `q * v2{c.w, c.w}` copies c.w into an even register first)
+        v2 s0[4], s1[4];
 #pragma unroll
         for (int i = 0; i < NB0; ++i) {
           const float4 c = ww0[64 * i], q0 = pp0[2 * i], q1 = pp0[2 * i + 1];
-          s0[0] = v2{q0.x, q0.y} * v2{c.x, c.x} + s0[0]; s0[1] = v2{q0.z, q0.w} * v2{c.y, c.y} + s0[1];
-          s0[2] = v2{q1.x, q1.y} * v2{c.z, c.z} + s0[2]; s0[3] = v2{q1.z, q1.w} * v2{c.w, c.w} + s0[3];
+          const v2 c01 = {c.x, c.y}, c23 = {c.z, c.w};
+          if (i == 0) {
+            s0[0] = f3_mel_mul_lo(v2{q0.x, q0.y}, c01); s0[1] = f3_mel_mul_hi(v2{q0.z, q0.w}, c01);
+            s0[2] = f3_mel_mul_lo(v2{q1.x, q1.y}, c23); s0[3] = f3_mel_mul_hi(v2{q1.z, q1.w}, c23);
+          } else {
+            s0[0] = f3_mel_fma_lo(v2{q0.x, q0.y}, c01, s0[0]); s0[1] = f3_mel_fma_hi(v2{q0.z, q0.w}, c01, s0[1]);
+            s0[2] = f3_mel_fma_lo(v2{q1.x, q1.y}, c23, s0[2]); s0[3] = f3_mel_fma_hi(v2{q1.z, q1.w}, c23, s0[3]);
+          }
         }
 #pragma unroll
         for (int i = 0; i < NB1; ++i) {
           const float4 c = ww1[64 * i], q0 = pp1[2 * i], q1 = pp1[2 * i + 1];
-          s1[0] = v2{q0.x, q0.y} * v2{c.x, c.x} + s1[0]; s1[1] = v2{q0.z, q0.w} * v2{c.y, c.y} + s1[1];
-          s1[2] = v2{q1.x, q1.y} * v2{c.z, c.z} + s1[2]; s1[3] = v2{q1.z, q1.w} * v2{c.w, c.w} + s1[3];
+          const v2 c01 = {c.x, c.y}, c23 = {c.z, c.w};
+          if (i == 0) {
+            s1[0] = f3_mel_mul_lo(v2{q0.x, q0.y}, c01); s1[1] = f3_mel_mul_hi(v2{q0.z, q0.w}, c01);
+            s1[2] = f3_mel_mul_lo(v2{q1.x, q1.y}, c23); s1[3] = f3_mel_mul_hi(v2{q1.z, q1.w}, c23);
+          } else {
+            s1[0] = f3_mel_fma_lo(v2{q0.x, q0.y}, c01, s1[0]); s1[1] = f3_mel_fma_hi(v2{q0.z, q0.w}, c01, s1[1]);
+            s1[2] = f3_mel_fma_lo(v2{q1.x, q1.y}, c23, s1[2]); s1[3] = f3_mel_fma_hi(v2{q1.z, q1.w}, c23, s1[3]);
+          }
         }
         const v2 m0 = (s0[0] + s0[1]) + (s0[2] + s0[3]), m1 = (s1[0] + s1[1]) + (s1[2] + s1[3]);
         const float L00 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(m0.x, amin));
@@ -413,7 +439,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       }
       }
 
-      // ---- take in the next pair's 8 new rows
+      if constexpr ((F3_EXP & 8) != 0) __builtin_amdgcn_s_setprio(0);
+      if constexpr ((F3_EXP & 16) != 0) __builtin_amdgcn_s_setprio(1);
+      // ---- take in the next pair's 8 new rows, straight into the registers P leaves free
       if (more) {
         float n[8];
         if (nint) {
@@ -426,9 +454,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
           for (int u = 0; u < 8; ++u) n[u] = XB[64 * u + lane];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { R[8 + i].y = n[i]; R[12 + i] = v2{n[i], n[4 + i]}; }
-        if constexpr (SPEC) {          // rows 12..19 of pair p + 1: sub-blocks t0 + 2 (p + 1) + 1, + 2, as (x, y) = R[12 + i]
-          v2 q = R[12] * R[12]; q = R[13] * R[13] + q; q = R[14] * R[14] + q; q = R[15] * R[15] + q;
+        for (int i = 0; i < 4; ++i) { P[i].y = n[i]; P[4 + i] = v2{n[i], n[4 + i]}; }
+        if constexpr (SPEC) {          // rows 12..19 of pair p + 1: sub-blocks t0 + 2 (p + 1) + 1, + 2, as (x, y) = P'[4 + i]
+          v2 q = P[4] * P[4]; q = P[5] * P[5] + q; q = P[6] * P[6] + q; q = P[7] * P[7] + q;
           if (sub2(q.x, q.y, 2 * p + 3, 3ull)) {
             bool bad = false;
 #pragma unroll
@@ -437,6 +465,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
           }
         }
       }
+    };
+
+#pragma unroll 1
+    for (int p = 0; p < npairs; p += 2) {
+      pair_body(Ra, Rb, p);
+      if (p + 1 < npairs) pair_body(Rb, Ra, p + 1);       // roles swapped; eight pairs (a whole block) end where they began
     }
     // ---- clip maximum of the log-mel (power_to_db's top_db reference)
     {

@@ -1,0 +1,266 @@
+// k_tail: everything behind the frame kernels for one clip in one workgroup -- power_to_db's clip-global clamp, the ortho
+// DCT-II, and the per-clip statistics -- with the MFCC rows never leaving the chip.
+// (reference call sites: audio_feature_extraction_toolkit/core/feature_extractor.py:127-134 librosa.feature.mfcc ->
+//  power_to_db(top_db=80) + scipy.fft.dct; :137-138 librosa.feature.delta; :141-150 mean / std / delta means;
+//  :164-178 rms statistics.  Shape that motivates it: 04_feature_extraction_experiment/feature_extraction.py:35-41,
+//  n_mfcc = 40 at 16 kHz / 512 / 128.)
+//
+// Why.  The two-kernel tail (k_dct16* then k_stats) writes the MFCC rows [clip][k][Tpad] to HBM and reads them back.  For the
+// speech configuration (40 coefficients, hop 128) that is 216 MB out + 213 MB in per 1000 clips -- more than the samples
+// themselves (640 MB) -- and a second launch.  Only 4K + 3 numbers per clip are wanted: sum and sum of squares per
+// coefficient (float64 accumulators, as k_stats), and the nine frames at either end of every row (the means of the two
+// Savitzky-Golay delta rows telescope to them, see k_stats).  So: a workgroup per clip walks the clip's log-mel spill
+// once in 16-frame tiles, multiplies each tile by the DCT images (exact-f32 MFMA, images in LDS: k_dct16l's loop), and
+// every lane adds the four coefficients it receives of its frame to its own float64 sums; the tiles that hold the
+// first / last nine frames also drop their values into a 18-column LDS table.  One reduction at the end.  The spill is
+// read once at HBM rate; nothing else moves.  Per-frame export (out_frames) keeps the two-kernel path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "afx_device.h"
+
+namespace afx {
+
+typedef float tl_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float tl_ord2f(uint32_t o) {
+  const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+// sum over the 16 lanes of a row (all lanes of the row end with the total); doubles go as two dwords through DPP-free
+// shuffles: this runs once per clip, not per tile
+__device__ __forceinline__ double tl_row_sum(double v) {
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double tl_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int kTailWaves = 4;
+
+template <int NCG>
+__global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __restrict__ clips,
+                                                          const ClipInfo* __restrict__ info,
+                                                          const float* __restrict__ dctP, KParams kp,
+                                                          const float* __restrict__ logmel,
+                                                          const float* __restrict__ rms_rows,
+                                                          float* __restrict__ stats,
+                                                          ClipInfo* __restrict__ info_out, int spec) {
+  extern __shared__ float tl_smem[];
+  const int M = kp.n_mels, K = kp.n_mfcc, S = M >> 4;     // S <= 8
+  float* const dct_tab = tl_smem;                          // [(g S + s) 4 + c][64 lanes]
+  float* const edge = dct_tab + NCG * S * 4 * 64;          // [k < 16 NCG][18]: frames 0..8, T-9..T-1 of row k
+  double* const part = reinterpret_cast<double*>(edge + NCG * 16 * 18 + (((NCG * 16 * 18) & 1) ? 1 : 0));   // [wave][k][2]
+  double* const red = part + kTailWaves * NCG * 16 * 2;   // block reductions of the RMS row: [wave][4]
+  const int clip = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const ClipInfo ci = info[clip];
+  const ClipDesc cd = clips[clip];
+  if (info_out && tid == 0) info_out[clip] = ci;           // the caller's copy (host memory the device can write)
+  float* const st = stats + (int64_t)clip * (4 * K + 3);
+  // a clip with fewer than 9 frames fails the MFCC rows (librosa.feature.delta raises) but still has an RMS row:
+  // extract_energy (F:153-179) only calls librosa.feature.rms
+  const bool energy_only = ci.status == AFX_CLIP_TOO_SHORT && cd.len >= 2 && ci.T >= 1;
+  if (ci.status != AFX_CLIP_OK) {                          // uniform per workgroup
+    for (int i = tid; i < 4 * K + (energy_only ? 0 : 3); i += kTailWaves * 64) st[i] = 0.f;
+    if (!energy_only) return;
+  }
+  const int T = ci.T;
+  const double invT = 1.0 / (double)T;
+
+  if (ci.status == AFX_CLIP_OK) {
+    for (int i = tid; i < NCG * S * 4 * 64; i += kTailWaves * 64) dct_tab[i] = dctP[i];
+    __syncthreads();
+    const float theta = tl_ord2f(ci.lmax_ord) - kp.top_db;
+    const int f = lane & 15, q = lane >> 4;
+    const int ntiles = (T + 15) >> 4;
+    // spec: the spill holds absolute frames (the frame kernel ran before the trim decision); trimmed frame t is frame start / hop + t
+    const int g0 = spec ? (int)(ci.start / kp.hop) : 0;
+    // frame-major spill [frame][mel]: lane (f, q) fetches filters 16 s + 4 q + {0..3} of frame f with one 16-byte load
+    // (a wave-load is a run of whole 64-byte pieces of 16 rows); rows past the clip's last frame are read but never used
+    // (the spill is allocated 16 frames beyond the batch's last row)
+    auto load_tile = [&](int tile, float4 (&x)[8]) {
+      const float* src = logmel + (cd.frame_base + g0 + tile * 16 + f) * (int64_t)M + q * 4;
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        x[s] = (s < S && tile < ntiles) ? *reinterpret_cast<const float4*>(src + s * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    double sm[NCG][4], sq[NCG][4];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sm[g][r] = 0.0; sq[g][r] = 0.0; }
+    float4 xc[8], xn[8];
+    int tile = wave;
+    load_tile(tile, xc);
+    for (; tile < ntiles; tile += kTailWaves) {
+      load_tile(tile + kTailWaves, xn);
+      tl_f32x4 acc[NCG][2];
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) { acc[g][0] = tl_f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = tl_f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        if (s < S) {
+          const float b0 = fmaxf(xc[s].x, theta), b1 = fmaxf(xc[s].y, theta);
+          const float b2 = fmaxf(xc[s].z, theta), b3 = fmaxf(xc[s].w, theta);
+#pragma unroll
+          for (int g = 0; g < NCG; ++g) {
+            const float* a = dct_tab + ((g * S + s) * 4) * 64 + lane;
+            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0, acc[g][0], 0, 0, 0);
+            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[64], b1, acc[g][1], 0, 0, 0);
+            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[128], b2, acc[g][0], 0, 0, 0);
+            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[192], b3, acc[g][1], 0, 0, 0);
+          }
+        }
+      }
+      const int t = tile * 16 + f;
+      const bool live = t < T;
+      const bool edge_tile = tile * 16 < 9 || tile * 16 + 16 > T - 9;      // wave-uniform: holds one of the 18 end frames
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        const tl_f32x4 r4 = acc[g][0] + acc[g][1];       // the same two-accumulator sum as k_dct16 / k_dct16l: identical rows
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double v = live ? (double)r4[r] : 0.0;
+          sm[g][r] += v; sq[g][r] = fma(v, v, sq[g][r]);
+        }
+        if (edge_tile && live) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k = g * 16 + q * 4 + r;
+            if (t < 9) edge[k * 18 + t] = r4[r];
+            if (t >= T - 9) edge[k * 18 + 9 + (t - (T - 9))] = r4[r];
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) xc[s] = xn[s];
+    }
+    // ---- per wave: totals of the 16 frame lanes of each coefficient row
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double a = tl_row_sum(sm[g][r]), b = tl_row_sum(sq[g][r]);
+        if (f == 0) {
+          const int k = g * 16 + q * 4 + r;
+          part[(wave * NCG * 16 + k) * 2] = a;
+          part[(wave * NCG * 16 + k) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    // ---- one thread per coefficient: mean, population std, and the means of the two delta rows from the row's ends
+    if (tid < K) {
+      const int row = tid;
+      double s = 0.0, ss = 0.0;
+#pragma unroll
+      for (int w = 0; w < kTailWaves; ++w) { s += part[(w * NCG * 16 + row) * 2]; ss += part[(w * NCG * 16 + row) * 2 + 1]; }
+      const double mean = s * invT;
+      const float meanf = (float)mean;
+      const double c = (double)meanf;
+      // sum (x - c)^2 = ss - 2 c s + T c^2 about the float32 mean c, as numpy's std (k_stats)
+      const double s2 = fmax(ss - 2.0 * c * s + (double)T * c * c, 0.0);
+      double h[9], g9[9];                                   // h[i] = x[i], g9[i] = x[T - 9 + i]
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { h[i] = (double)edge[row * 18 + i]; g9[i] = (double)edge[row * 18 + 9 + i]; }
+      // Both savgol filters (width 9, polyorder = deriv = order, mode 'interp') are differences: their sums over the frames
+      // telescope to the nine frames at either end; frames 0..3 / T-4..T-1 repeat frame 4 / T-5 (k_stats, same arithmetic)
+      auto D1 = [](const double* cc) {
+        return (4.0 * (cc[4] - cc[-4]) + 3.0 * (cc[3] - cc[-3]) + 2.0 * (cc[2] - cc[-2]) + (cc[1] - cc[-1])) * (1.0 / 60.0);
+      };
+      auto D2 = [](const double* cc) {
+        return (28.0 * (cc[4] + cc[-4]) + 7.0 * (cc[3] + cc[-3]) - 8.0 * (cc[2] + cc[-2]) - 17.0 * (cc[1] + cc[-1]) - 20.0 * cc[0]) * (1.0 / 462.0);
+      };
+      const double w2[5] = {0.0, -17.0, -8.0, 7.0, 28.0};
+      double sd1 = 0.0, sd2 = 0.0;
+#pragma unroll
+      for (int k = 1; k <= 4; ++k) {
+        double head = 0.0, tail = 0.0, hl = 0.0, hr = 0.0, tl = 0.0, tr = 0.0;
+#pragma unroll
+        for (int i = 4 - k; i <= 3 + k; ++i) head += h[i];          // x[4 - k .. 3 + k]
+#pragma unroll
+        for (int i = 5 - k; i <= 4 + k; ++i) tail += g9[i];         // x[T - 4 - k .. T - 5 + k]
+#pragma unroll
+        for (int i = 4 - k; i <= 3; ++i) hl += h[i];
+#pragma unroll
+        for (int i = 4; i <= 3 + k; ++i) hr += h[i];
+#pragma unroll
+        for (int i = 5 - k; i <= 4; ++i) tl += g9[i];
+#pragma unroll
+        for (int i = 5; i <= 4 + k; ++i) tr += g9[i];
+        sd1 += (double)k * (tail - head);
+        sd2 += w2[k] * ((hl - hr) + (tr - tl));
+      }
+      sd1 = sd1 * (1.0 / 60.0) + 4.0 * ((double)(float)D1(h + 4) + (double)(float)D1(g9 + 4));
+      sd2 = sd2 * (1.0 / 462.0) + 4.0 * ((double)(float)D2(h + 4) + (double)(float)D2(g9 + 4));
+      st[row] = meanf;
+      st[K + row] = (float)sqrt(s2 * invT);
+      st[2 * K + row] = (float)(sd1 * invT);
+      st[3 * K + row] = (float)(sd2 * invT);
+    }
+  }
+
+  // ---- RMS row: mean, population std about the float32 mean, peak to peak (F:171-178)
+  {
+    const float* r = rms_rows + cd.frame_base;
+    double s = 0.0;
+    float mx = -INFINITY, mn = INFINITY;
+    for (int t = tid; t < T; t += kTailWaves * 64) {
+      const float v = r[t];
+      s += (double)v; mx = fmaxf(mx, v); mn = fminf(mn, v);
+    }
+    s = tl_wave_sum(s);
+    double dmx = (double)mx, dmn = (double)mn;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { dmx = fmax(dmx, __shfl_xor(dmx, o)); dmn = fmin(dmn, __shfl_xor(dmn, o)); }
+    if (lane == 0) { red[wave * 4] = s; red[wave * 4 + 1] = dmx; red[wave * 4 + 2] = dmn; }
+    __syncthreads();
+    double tot = 0.0, gmx = -INFINITY, gmn = INFINITY;
+#pragma unroll
+    for (int w = 0; w < kTailWaves; ++w) { tot += red[w * 4]; gmx = fmax(gmx, red[w * 4 + 1]); gmn = fmin(gmn, red[w * 4 + 2]); }
+    const float meanf = (float)(tot * invT);
+    double s2 = 0.0;
+    for (int t = tid; t < T; t += kTailWaves * 64) { const float d = r[t] - meanf; s2 += (double)d * (double)d; }
+    s2 = tl_wave_sum(s2);
+    if (lane == 0) red[wave * 4 + 3] = s2;
+    __syncthreads();
+    if (tid == 0) {
+      double v2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < kTailWaves; ++w) v2 += red[w * 4 + 3];
+      st[4 * K] = meanf;
+      st[4 * K + 1] = (float)sqrt(v2 * invT);
+      st[4 * K + 2] = (float)gmx - (float)gmn;
+    }
+  }
+}
+
+bool tail_eligible(const KParams& kp, const DevTables& tb) {
+  return tb.dctP != nullptr && kp.n_mels % 16 == 0 && kp.n_mels <= 128 && kp.n_mfcc <= 48;
+}
+
+size_t tail_lds_bytes(int ncg, int n_mels) {
+  const size_t tab = (size_t)ncg * (n_mels / 16) * 4 * 64, edge = (size_t)ncg * 16 * 18 + 1;
+  return (tab + edge) * sizeof(float) + ((size_t)kTailWaves * ncg * 16 * 2 + kTailWaves * 4) * sizeof(double) + 16;
+}
+
+hipError_t launch_tail(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb, const KParams& kp,
+                       const float* logmel, const float* rms_rows, float* stats, ClipInfo* info_out, int n_clips, int spec) {
+  const int ncg = (kp.n_mfcc + 15) / 16;
+  const size_t lds = tail_lds_bytes(ncg, kp.n_mels);
+  dim3 grid(n_clips), block(kTailWaves * 64);
+  switch (ncg) {
+    case 1: hipLaunchKernelGGL((k_tail<1>), grid, block, lds, s, clips, info, tb.dctP, kp, logmel, rms_rows, stats, info_out, spec); break;
+    case 2: hipLaunchKernelGGL((k_tail<2>), grid, block, lds, s, clips, info, tb.dctP, kp, logmel, rms_rows, stats, info_out, spec); break;
+    case 3: hipLaunchKernelGGL((k_tail<3>), grid, block, lds, s, clips, info, tb.dctP, kp, logmel, rms_rows, stats, info_out, spec); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace afx

@@ -151,3 +151,46 @@ def test_distinct_ragged_batches_through_two_plans(sr, n_fft, hop, n_mfcc):
     for p in plans:
         p.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,n_fft,hop,n_mfcc", [(22050, 1024, 256, 13), (16000, 512, 128, 40), (44100, 2048, 512, 20),
+                                                  (22050, 1024, 256, 40), (16000, 512, 128, 16)])
+def test_fused_tail_equals_the_two_kernel_tail(sr, n_fft, hop, n_mfcc):
+    """k_tail (clamp + DCT + statistics per clip, MFCC rows never written; what a statistics-only batch runs) against the
+    k_dct16* + k_stats pair that a batch with per-frame output still runs: same statuses, trims and frame counts, and the
+    statistics equal up to the order of the float64 row sums; and both against the oracle.  Clips: ordinary, silence-padded
+    (a real trim, frame offset > 0), 9 and 10 frames (the delta's minimum), fewer than 9 (energy only), non-finite."""
+    from tests.parity import check_stats, oracle_stats
+    clips = [make_clip(400 + i, sr, 0.6 + 0.21 * (i % 7), speechy=(i % 3 == 0)) for i in range(37)]
+    clips[3] = clips[3][: 9 * hop - 1].copy()        # 9 frames
+    clips[4] = clips[4][: 10 * hop - 3].copy()       # 10 frames
+    clips[5] = clips[5][: 5 * hop].copy()            # 6 frames: MFCC fails, energy stays
+    clips[6] = clips[6].copy(); clips[6][777] = np.inf
+    clips[7] = clips[7][:1].copy()
+    lens = np.array([c.size for c in clips], np.int64)
+    offs = np.zeros(len(clips), np.int64)
+    offs[1:] = np.cumsum((lens + 3) // 4 * 4)[:-1]
+    buf = np.zeros(int(offs[-1] + lens[-1]) + 8, np.float32)
+    for c, o in zip(clips, offs):
+        buf[o:o + c.size] = c
+    ctx = N.Context(0)
+    plan = N.Plan(ctx, N.make_params(sr, n_fft, hop, n_mfcc))
+    two = plan.extract_batch(buf, offs, lens, want_frames=True)
+    one = plan.extract_batch(buf, offs, lens)
+    plan.close()
+    ctx.close()
+    assert np.array_equal(one["status"], two["status"]) and np.array_equal(one["trim"], two["trim"])
+    assert np.array_equal(one["nframes"], two["nframes"])
+    assert one["status"][5] == N.CLIP_TOO_SHORT and one["status"][6] == N.CLIP_NONFINITE and one["status"][7] == N.CLIP_TOO_SHORT
+    K = n_mfcc
+    for i in range(len(clips)):
+        a, b = one["stats"][i].astype(np.float64), two["stats"][i].astype(np.float64)
+        if one["status"][i] == 0:
+            scale = np.maximum(np.abs(b), 1e-3 * np.abs(b[:K]).max())
+            assert (np.abs(a - b) <= 2e-6 * scale).all(), (i, np.abs(a - b).max())
+            if i % 4 == 0 or i in (3, 4):
+                check_stats(one["stats"][i], oracle_stats(clips[i], sr, n_fft, hop, K), K, f"fused tail clip {i}")
+        else:
+            assert np.array_equal(a, b), i                           # zeros, or the energy statistics alone
+    assert one["stats"][5][4 * K] > 0.0 and not one["stats"][5][:4 * K].any()
