@@ -41,10 +41,6 @@
 #include "afx_frames3.h"
 #include "afx_frames3_dev.h"
 
-#ifndef F3_EXP
-#define F3_EXP 0          // experiment bits (same-box A/B builds only; the shipped value is what the A/B left standing)
-#endif
-
 namespace afx {
 
 size_t frames3_lds_bytes(int waves, const F3Tables& ft) {
@@ -94,8 +90,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
   // twiddles as 16-byte entries, one LDS read for two: an LDS instruction costs the SIMD ~8 cycles of issue whatever its width
   float4* const T2q = reinterpret_cast<float4*>(tabs);        // [rr][16]: (W_128^(c 2rr), W_128^(c (2rr + 1))), rr < 4
   float4* const T3q = reinterpret_cast<float4*>(tabs + 256);  // [r-1][lane]: (W_1024^(ja r), W_1024^(jb r))
+  // with the schedule compiled in, every table sits at a compile-time LDS address: the lane-indexed ones (weights, window,
+  // last-pass twiddles) can then share one address register (16 * lane) and differ by their immediate offsets
+  const int mel_wfloats = NB0 > 0 ? (NB0 + NB1) * 256 : ft.mel_wfloats;
+  const int mel_rounds = NB0 > 0 ? 2 : ft.mel_rounds;
   float* const MW = tabs + kF3TabFloats;                      // mel weights [round][batch][lane][4]
-  int* const MM = reinterpret_cast<int*>(MW + ft.mel_wfloats);   // mel meta [round][lane]
+  int* const MM = reinterpret_cast<int*>(MW + mel_wfloats);   // mel meta [round][lane]
   v2* const E = reinterpret_cast<v2*>(smem + wave * kF3ExFloats);
   float* const XB = reinterpret_cast<float*>(E);
 
@@ -111,14 +111,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
 #pragma unroll
       for (int r = 1; r < 8; ++r) { const v2 ta = W(tid * r), tb = W(jbt * r); T3q[(r - 1) * 64 + tid] = float4{ta.x, ta.y, tb.x, tb.y}; }
     }
-    for (int i = tid; i < ft.mel_wfloats; i += WAVES * 64) MW[i] = ft.mel_w[i];
-    for (int i = tid; i < ft.mel_rounds * 64; i += WAVES * 64) MM[i] = ft.mel_meta[i];
+    for (int i = tid; i < mel_wfloats; i += WAVES * 64) MW[i] = ft.mel_w[i];
+    for (int i = tid; i < mel_rounds * 64; i += WAVES * 64) MM[i] = ft.mel_meta[i];
     for (int i = lane; i < kF3ExFloats; i += 64) XB[i] = 0.f;
   }
   // the lane's 16 window values (w[n] = w[N - n]) x 0.5 as a 4 KB table [u / 4][lane] of quadruples, read back per frame
   // pair (four 16-byte reads): 16 registers less, so that the kernel fits 128 registers at 16 waves per CU and, at 12
   // waves, leaves the other streams' bandwidth-bound kernels (DCT 74 registers, statistics 56) room beside it
-  float4* const WT = reinterpret_cast<float4*>(MM + ft.mel_rounds * 64);
+  float4* const WT = reinterpret_cast<float4*>(MM + mel_rounds * 64);
   if (tid < 64) {
     float wreg[16];
 #pragma unroll
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     if constexpr (FMT == AFX_FMT_S16) return (float)base[idx] * (1.0f / 32768.0f);
     else return base[idx];
   };
-  const int n_rounds = ft.mel_rounds;
+  const int n_rounds = mel_rounds;
   const int meta0 = MM[lane], meta1 = MM[64 + lane];       // straight-line schedule: the lane's two filters
   const unsigned mf0 = (meta0 >> 11) & 511, mf1 = (meta1 >> 11) & 511;
   const float amin = kp.amin;
@@ -266,9 +266,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         z[4 * v + 2] = src[2] * v2{w.z, w.z}; z[4 * v + 3] = src[3] * v2{w.w, w.w};
       }
       // the next pair shares rows 8..19 (Q) and brings 8 new ones, n[0..7] = rows 20..27 of this pair's window; they go
-      // where P is (dead from here on):  P'[i] = (Q[4 + i].y, n[i]),  P'[4 + i] = (n[i], n[4 + i])
-#pragma unroll
-      for (int i = 0; i < 4; ++i) P[i].x = Q[4 + i].y;
+      // where P is (dead from here on, its 16 registers free across the FFT and the mel phase):
+      //   P'[i] = (Q[4 + i].y, n[i]),  P'[4 + i] = (n[i], n[4 + i])
       const bool more = p + 1 < npairs || chain;           // the next pair may be the next block's first
       const int jn = 512 * (p + 1) + 768;                  // staged samples [jn, jn + 512)
       const bool nint = more && (blk_int || interior(jn, jn + 512));
@@ -277,7 +276,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       f3_dft16(z, H, W1, W3);
       if (!F3_SKIP(0x200)) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { if constexpr ((F3_EXP & 1) != 0) stv(e1w + k, z[k]); else e1w[k] = z[k]; }
+      for (int k = 0; k < 16; ++k) stv(e1w + k, z[k]);       // stv: two ds_write_b64 (2 x 6 cycles), not a merged ds_write2_b64 (13)
 #pragma unroll
       for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 68 * u);
       }
@@ -297,10 +296,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         f3_dft8(xa, H); f3_dft8(xb, H);
         if (!F3_SKIP(0x2000)) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          if constexpr ((F3_EXP & 2) != 0) { stv(e2w + 16 * r, xa[r]); stv(e2w + 16 * r + 512, xb[r]); }
-          else { e2w[16 * r] = xa[r]; e2w[16 * r + 512] = xb[r]; }
-        }
+        for (int r = 0; r < 8; ++r) { stv(e2w + 16 * r, xa[r]); stv(e2w + 16 * r + 512, xb[r]); }
         } else {
 #pragma unroll
           for (int r = 0; r < 8; ++r) { z[2 * r] = xa[r]; z[2 * r + 1] = xb[r]; }
@@ -332,13 +328,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       for (int s = 0; s < 4; s += 2) {
         v2 p0, p1;
         sqsum2(A[s] + B[7 - s], A[s] - B[7 - s], A[s + 1] + B[6 - s], A[s + 1] - B[6 - s], p0, p1);
-        if constexpr ((F3_EXP & 4) != 0) { stv(ea + 128 * s, p0); stv(ea + 128 * (s + 1), p1); } else { ea[128 * s] = p0; ea[128 * (s + 1)] = p1; }
+        ea[128 * s] = p0; ea[128 * (s + 1)] = p1;
       }
 #pragma unroll
       for (int s = 4; s < 8; s += 2) {
         v2 p0, p1;
         sqsum2(A[s] + B[7 - s], A[s] - B[7 - s], A[s + 1] + B[6 - s], A[s + 1] - B[6 - s], p0, p1);
-        if constexpr ((F3_EXP & 4) != 0) { stv(eb + 384 - 128 * (s - 4), p0); stv(eb + 384 - 128 * (s - 3), p1); } else { eb[384 - 128 * (s - 4)] = p0; eb[384 - 128 * (s - 3)] = p1; }
+        eb[384 - 128 * (s - 4)] = p0; eb[384 - 128 * (s - 3)] = p1;
       }
       if (lane == 0) E[512] = v2{4.f * nyq.x * nyq.x, 4.f * nyq.y * nyq.y};
       } else {
@@ -354,8 +350,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
         for (int u = 0; u < 8; ++u) { ny[u] = row_ld(sp + jn, 64 * u + lane); nyp[u] = row_ld(sp + jn - 1, 64 * u + lane); }
       }
       // ---- mel + dB
-      if constexpr ((F3_EXP & 8) != 0) __builtin_amdgcn_s_setprio(1);
-      if constexpr ((F3_EXP & 16) != 0) __builtin_amdgcn_s_setprio(0);
+      // The kernel waits on the LDS pipe (SQ_WAIT_INST_LDS is a quarter of a wave's life); a wave in the mel phase -- 27 reads
+      // in front of 36 FMAs -- goes ahead of its three SIMD mates that are in their FFT (same-box A/B: frame kernel -2.5 %)
+      __builtin_amdgcn_s_setprio(1);
       const bool vA = 2 * p < Tleft, vB = 2 * p + 1 < Tleft;
       float* const rowA = tile + (unsigned)(2 * p * M);
       if constexpr (NB0 > 0) {
@@ -439,8 +436,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       }
       }
 
-      if constexpr ((F3_EXP & 8) != 0) __builtin_amdgcn_s_setprio(0);
-      if constexpr ((F3_EXP & 16) != 0) __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(0);
       // ---- take in the next pair's 8 new rows, straight into the registers P leaves free
       if (more) {
         float n[8];
@@ -454,7 +450,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
           for (int u = 0; u < 8; ++u) n[u] = XB[64 * u + lane];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { P[i].y = n[i]; P[4 + i] = v2{n[i], n[4 + i]}; }
+        for (int i = 0; i < 4; ++i) { P[i] = v2{Q[4 + i].y, n[i]}; P[4 + i] = v2{n[i], n[4 + i]}; }
         if constexpr (SPEC) {          // rows 12..19 of pair p + 1: sub-blocks t0 + 2 (p + 1) + 1, + 2, as (x, y) = P'[4 + i]
           v2 q = P[4] * P[4]; q = P[5] * P[5] + q; q = P[6] * P[6] + q; q = P[7] * P[7] + q;
           if (sub2(q.x, q.y, 2 * p + 3, 3ull)) {
@@ -492,7 +488,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     bd = blocks[b];
     }
   }
-  } while (f3_runs_next(runs, work_ctr, nblocks, lane));
+  } while (f3_runs_next(runs, work_ctr, nblocks, (int)(gridDim.x * WAVES), lane));
 #ifdef AFX_F3_DEBUG
   if (SPEC && lane == 0 && wg < 8192) {
     g_f3_stamps[4 * wg] = stamp0; g_f3_stamps[4 * wg + 1] = stamp1; g_f3_stamps[4 * wg + 2] = wall_clock64();
@@ -739,6 +735,7 @@ static hipError_t launch_frames3_w(hipStream_t s, const void* samples, ClipInfo*
                                    float* logmel, float* blockmax, float* bsum, int* work_ctr, int n_cu) {
   // straight-line mel schedules compiled in: two rounds of width 1
   const bool two = ft.mel_rounds == 2 && ((ft.mel_rp[0] >> 4) & 15) == 1 && ((ft.mel_rp[1] >> 4) & 15) == 1 && ft.mel_all_own &&
+                   ft.mel_wfloats == (int)((ft.mel_rp[0] & 15) + (ft.mel_rp[1] & 15)) * 256 && (ft.mel_rp[1] >> 8) == (ft.mel_rp[0] & 15) * 256 &&
                    !dev_env().f3_generic_mel;
   const int nb0 = ft.mel_rp[0] & 15, nb1 = ft.mel_rp[1] & 15;
   if (two && nb0 == 2 && nb1 == 7)

@@ -189,15 +189,17 @@ __device__ __forceinline__ uint32_t f3_ord(float f) {
 // launch, while one ticket per block makes every wave queue on one L2 atomic (79 000 of them slowed the 512 / 128
 // kernel by 60 %).  Without a counter (the short list launch): blocks wg, wg + waves, ...
 struct F3Runs {
-  int b_lo, b_hi, stride, dyn0, cA, cB, waves;
+  int b_lo, b_hi, stride;
 };
+// the ticket geometry is recomputed from (nblocks, total_waves) where a ticket is drawn -- a few scalar instructions once per
+// run -- instead of living in four more scalar registers across the pair loop (the kernels sit at the scalar file's limit;
+// a spilled scalar register costs a vector register)
 __device__ __forceinline__ F3Runs f3_runs_init(const int* work_ctr, int nblocks, int total_waves, int wg, bool contiguous) {
   F3Runs r;
-  r.waves = total_waves; r.stride = 1; r.dyn0 = 0; r.cA = 1; r.cB = 1;
+  r.stride = 1;
   if (work_ctr) {
     const int C0 = nblocks / (2 * total_waves);
-    r.b_lo = wg * C0; r.b_hi = r.b_lo + C0; r.dyn0 = total_waves * C0;
-    r.cA = C0 / 2 > 1 ? C0 / 2 : 1; r.cB = C0 / 3 > 1 ? C0 / 3 : 1;
+    r.b_lo = wg * C0; r.b_hi = r.b_lo + C0;
   } else if (contiguous) {
     r.b_lo = (int)((long long)wg * nblocks / total_waves); r.b_hi = (int)((long long)(wg + 1) * nblocks / total_waves);
   } else {
@@ -206,15 +208,17 @@ __device__ __forceinline__ F3Runs f3_runs_init(const int* work_ctr, int nblocks,
   return r;
 }
 // the wave's next run; false when the list is exhausted (wave-uniform)
-__device__ __forceinline__ bool f3_runs_next(F3Runs& r, int* work_ctr, int nblocks, int lane) {
+__device__ __forceinline__ bool f3_runs_next(F3Runs& r, int* work_ctr, int nblocks, int total_waves, int lane) {
   if (!work_ctr) return false;
   int t = 0;
   if (lane == 0) t = atomicAdd(work_ctr, 1);
   t = __builtin_amdgcn_readfirstlane(t);
+  const int C0 = nblocks / (2 * total_waves), dyn0 = total_waves * C0;
+  const int cA = C0 / 2 > 1 ? C0 / 2 : 1, cB = C0 / 3 > 1 ? C0 / 3 : 1;
   int c = 1;
-  if (t < r.waves) { r.b_lo = r.dyn0 + r.cA * t; c = r.cA; }
-  else if (t < 2 * r.waves) { r.b_lo = r.dyn0 + r.cA * r.waves + r.cB * (t - r.waves); c = r.cB; }
-  else r.b_lo = r.dyn0 + (r.cA + r.cB) * r.waves + (t - 2 * r.waves);
+  if (t < total_waves) { r.b_lo = dyn0 + cA * t; c = cA; }
+  else if (t < 2 * total_waves) { r.b_lo = dyn0 + cA * total_waves + cB * (t - total_waves); c = cB; }
+  else r.b_lo = dyn0 + (cA + cB) * total_waves + (t - 2 * total_waves);
   if (r.b_lo >= nblocks) return false;
   r.b_hi = r.b_lo + c < nblocks ? r.b_lo + c : nblocks;
   return true;

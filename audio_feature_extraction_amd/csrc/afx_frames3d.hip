@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
       else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx)); }
     }
   }
-  } while (f3_runs_next(runs, work_ctr, nblocks, lane));
+  } while (f3_runs_next(runs, work_ctr, nblocks, (int)(gridDim.x * WAVES), lane));
 }
 
 int frames3d_waves(const F3Tables& ft) {

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
     bd = blocks[b];
     }
   }
-  } while (f3_runs_next(runs, work_ctr, nblocks, lane));
+  } while (f3_runs_next(runs, work_ctr, nblocks, (int)(gridDim.x * WAVES), lane));
 }
 
 int frames3s_waves(const F3Tables& ft) {
