@@ -211,7 +211,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
     auto interior = [&](int j0, int j1) -> bool {         // every sample of [j0, j1) and its predecessor exists and is kept
       return (j0 - 1 >= bd.have_lo) && (j1 <= bd.have_hi) && (j0 >= bd.keep_lo) && (j1 <= bd.keep_hi);
     };
+    // The paths a pair rarely takes (a clip edge, a trimmed span, a non-finite sum) read the block's record again through
+    // an opaque index -- scalar loads where they are needed -- instead of pinning ten of its words in scalar registers
+    // across the pair loop: the kernel sits at the scalar file's limit, and a spilled scalar register costs a vector one
+    auto interior_r = [&](int j0, int j1) -> bool {
+      const BlockDesc& r = blocks[f3_opaque(b)];
+      return (j0 - 1 >= r.have_lo) && (j1 <= r.have_hi) && (j0 >= r.keep_lo) && (j1 <= r.keep_hi);
+    };
     auto edge_sample = [&](int j) -> float {              // pre-emphasised, trim-masked sample j (clamped loads)
+      const BlockDesc& bd = blocks[f3_opaque(b)];
       const int lo = bd.have_lo, hi = bd.have_hi - 1;
       const int jc = j < lo ? lo : (j > hi ? hi : j), jp = (j - 1) < lo ? lo : ((j - 1) > hi ? hi : (j - 1));
       const float y = (jc == j) ? raw_ld(sbase + jc) : 0.f;
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       //   P'[i] = (Q[4 + i].y, n[i]),  P'[4 + i] = (n[i], n[4 + i])
       const bool more = p + 1 < npairs || chain;           // the next pair may be the next block's first
       const int jn = 512 * (p + 1) + 768;                  // staged samples [jn, jn + 512)
-      const bool nint = more && (blk_int || interior(jn, jn + 512));
+      const bool nint = more && (blk_int || interior_r(jn, jn + 512));
 
       // ---- pass 1 + exchange 1
       f3_dft16(z, H, W1, W3);
@@ -444,8 +452,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
 #pragma unroll
           for (int u = 0; u < 8; ++u) n[u] = f3_pre1(ny[u], nyp[u], b1);
         } else {
+          // (the rare path: its sample indices are rebuilt from an opaque copy of jn, or the compiler carries three
+          // lane-indexed induction registers through every pair for it)
+          const int jn_e = f3_opaque(jn);
 #pragma unroll 1
-          for (int u = 0; u < 8; ++u) XB[64 * u + lane] = edge_sample(jn + 64 * u + lane);
+          for (int u = 0; u < 8; ++u) XB[64 * u + lane] = edge_sample(jn_e + 64 * u + lane);
 #pragma unroll
           for (int u = 0; u < 8; ++u) n[u] = XB[64 * u + lane];
         }
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
             bool bad = false;
 #pragma unroll
             for (int u = 0; u < 8; ++u) bad |= !isfinite(n[u]);
-            flag_nonfinite(bd, bad);
+            flag_nonfinite(blocks[f3_opaque(b)], bad);
           }
         }
       }
@@ -476,8 +487,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
       const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
       const float mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-      if constexpr (SPEC) { if (lane == 0) blockmax[b] = mx; sub_store(bd); }
-      else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[bd.clip].lmax_ord, f3_ord(mx)); }
+      const BlockDesc& be = blocks[f3_opaque(b)];          // read again: see interior_r
+      if constexpr (SPEC) { if (lane == 0) blockmax[b] = mx; sub_store(be); }
+      else { if (lane == 0 && mx > -INFINITY) atomicMax(&info[be.clip].lmax_ord, f3_ord(mx)); }
     }
 #ifdef AFX_F3_DEBUG
     if (SPEC && lane == 0 && b < 65536) g_f3_blk[b] = wall_clock64();

@@ -176,6 +176,8 @@ __device__ __forceinline__ uint32_t f3_ord(float f) {
   const uint32_t u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// a wave-uniform value the optimizer may not trace back to its definition (no strength reduction across loop trips)
+__device__ __forceinline__ int f3_opaque(int x) { asm volatile("" : "+s"(x)); return x; }
 // timing-only ablation switches (libafx built with -DAFX_F3_DEBUG, AFX_DEBUG_SKIP bits << 8 in kp.flags); results invalid
 #ifdef AFX_F3_DEBUG
 #define F3_SKIP(bit) ((kp.flags & (bit)) != 0)
