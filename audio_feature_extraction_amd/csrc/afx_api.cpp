@@ -288,6 +288,10 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
     pl->f3.mel_rounds = t.f3mel.rounds; pl->f3.mel_wfloats = (int32_t)t.f3mel.w.size();
     pl->f3.mel_all_own = 1;                        // every lane of every round is the owner of a filter (width-1 rounds, all lanes used)
     for (size_t i = 0; i < t.f3mel.meta.size(); ++i) if (!(t.f3mel.meta[i] & (1 << 20))) pl->f3.mel_all_own = 0;
+    pl->f3.mel_own_w1 = 1;
+    for (int r = 0; r < t.f3mel.rounds; ++r)
+      if (t.f3mel.width[r] == 1)
+        for (int l = 0; l < 64; ++l) if (!(t.f3mel.meta[(size_t)r * 64 + l] & (1 << 20))) pl->f3.mel_own_w1 = 0;
     for (int r = 0; r < kF3MaxRounds; ++r)
       pl->f3.mel_rp[r] = (uint32_t)t.f3mel.nb[r] | ((uint32_t)t.f3mel.width[r] << 4) | ((uint32_t)t.f3mel.woff[r] << 8);
   }

@@ -38,6 +38,7 @@ struct F3Tables {
   int32_t mel_rounds;
   int32_t mel_wfloats;
   int32_t mel_all_own;      // every (round, lane) owns a filter: the straight-line schedule stores without an owner test
+  int32_t mel_own_w1;       // the same for the rounds of width 1 alone (k_frames3s's compiled-in schedule mixes widths)
   uint32_t mel_rp[kF3MaxRounds];   // per round: batches | width << 4 | weight offset (floats) << 8
 };
 

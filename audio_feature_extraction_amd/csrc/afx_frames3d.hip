@@ -28,7 +28,10 @@ size_t frames3d_lds_bytes(int waves, const F3Tables& ft) {
   return (size_t)(waves * kF3ExFloats + kF3dTabFloats + ft.mel_wfloats + ft.mel_rounds * 64) * sizeof(float);
 }
 
-template <int FMT, int WAVES, bool SPEC>
+// NBS > 0: the mel schedule is known at compile time -- up to four rounds of width 1 in which every lane owns a filter, their
+// batch counts the nibbles of NBS from the first round up (the reference's 16 kHz / 128 mels plans 1, 1, 2, 4: NBS 0x4211) --
+// and is walked as straight-line code, every read of a round in flight before its first FMA.  NBS = 0: any schedule.
+template <int FMT, int WAVES, bool SPEC, int NBS>
 __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict__ samples,
                                                          ClipInfo* __restrict__ info,
                                                          const BlockDesc* __restrict__ blocks, int nblocks,
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
       // ---- pass 1 + exchange 1 (this half's image)
       f3_dft16(z, H, W1, W3);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) e1w[k] = z[k];
+      for (int k = 0; k < 16; ++k) stv(e1w + k, z[k]);       // unmerged 8-byte stores: 2 x 6 LDS cycles against 13 for ds_write2_b64
 #pragma unroll
       for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 34 * u);
       // ---- pass 2 + exchange 2
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
         for (int r = 1; r < 8; ++r) cmul2(xa[r], tw[r], xb[r], tw[r]);
         f3_dft8(xa, H); f3_dft8(xb, H);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { e2w[16 * r] = xa[r]; e2w[16 * r + 256] = xb[r]; }
+        for (int r = 0; r < 8; ++r) { stv(e2w + 16 * r, xa[r]); stv(e2w + 16 * r + 256, xb[r]); }
       }
       // ---- pass 3: four radix-4 butterflies, j = l', jb0, l' + 32, 96 - l'
       v2 A0[4], B0[4], A1[4], B1[4];
@@ -242,6 +245,41 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
       const int fA = 4 * it + 2 * half;
       const bool vA = fA < Tleft, vB = fA + 1 < Tleft;
       float* const rowA = tile + (unsigned)(fA * M);
+      __builtin_amdgcn_s_setprio(1);          // a wave in its mel phase (LDS reads) goes ahead of its SIMD mates' FFTs: k_frames3
+      if constexpr (NBS > 0) {
+        int woff = 0;
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+          constexpr int kNbs = NBS;
+          const int nb = (kNbs >> (4 * rd)) & 15;
+          if (nb == 0) break;
+          const int meta = MM[rd * 64 + lane];
+          const float4* pp = reinterpret_cast<const float4*>(E + (meta & 2047));
+          const float4* ww = reinterpret_cast<const float4*>(MW + woff) + lane;
+          woff += nb * 256;
+          v2 sa[4];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (i < nb) {
+              const float4 c = ww[64 * i], q0 = pp[2 * i], q1 = pp[2 * i + 1];
+              const v2 c01 = {c.x, c.y}, c23 = {c.z, c.w};
+              if (i == 0) {
+                sa[0] = f3_mel_mul_lo(v2{q0.x, q0.y}, c01); sa[1] = f3_mel_mul_hi(v2{q0.z, q0.w}, c01);
+                sa[2] = f3_mel_mul_lo(v2{q1.x, q1.y}, c23); sa[3] = f3_mel_mul_hi(v2{q1.z, q1.w}, c23);
+              } else {
+                sa[0] = f3_mel_fma_lo(v2{q0.x, q0.y}, c01, sa[0]); sa[1] = f3_mel_fma_hi(v2{q0.z, q0.w}, c01, sa[1]);
+                sa[2] = f3_mel_fma_lo(v2{q1.x, q1.y}, c23, sa[2]); sa[3] = f3_mel_fma_hi(v2{q1.z, q1.w}, c23, sa[3]);
+              }
+            }
+          }
+          const v2 acc = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+          const float L0 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(acc.x, amin));
+          const float L1 = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(acc.y, amin));
+          const unsigned m = (meta >> 11) & 511;          // every lane owns its filter (launch_frames3d checks)
+          if (vA) { rowA[m] = L0; lmax = f3_max(lmax, L0); }
+          if (vB) { rowA[M + m] = L1; lmax = f3_max(lmax, L1); }
+        }
+      } else {
 #pragma unroll 1
       for (int rd = 0; rd < n_rounds; ++rd) {
         const uint32_t rp = ft.mel_rp[rd];
@@ -271,6 +309,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
           if (vB) { rowA[M + m] = L1; lmax = f3_max(lmax, L1); }
         }
       }
+      }
+      __builtin_amdgcn_s_setprio(0);
     }
     {
       float v = lmax;
@@ -292,7 +332,7 @@ int frames3d_waves(const F3Tables& ft) {
   return frames3d_lds_bytes(16, ft) <= 160 * 1024 ? 16 : 12;
 }
 
-template <int FMT, int WAVES, bool SPEC>
+template <int FMT, int WAVES, bool SPEC, int NBS>
 static hipError_t launch_frames3d_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
                                     int nblocks, const int* nblocks_dev, const F3Tables& ft, const KParams& kp,
                                     float* logmel, float* blockmax, float* bsum, int* work_ctr, int n_cu) {
@@ -301,13 +341,13 @@ static hipError_t launch_frames3d_t(hipStream_t s, const void* samples, ClipInfo
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3d<FMT, WAVES, SPEC>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3d<FMT, WAVES, SPEC, NBS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
   const int grid = std::max(1, std::min(n_cu, (nblocks + WAVES - 1) / WAVES));
-  hipLaunchKernelGGL((k_frames3d<FMT, WAVES, SPEC>), dim3(grid), dim3(WAVES * 64), frames3d_lds_bytes(WAVES, ft), s,
+  hipLaunchKernelGGL((k_frames3d<FMT, WAVES, SPEC, NBS>), dim3(grid), dim3(WAVES * 64), frames3d_lds_bytes(WAVES, ft), s,
                      samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr);
   return hipGetLastError();
 }
@@ -316,12 +356,22 @@ hipError_t launch_frames3d(hipStream_t s, const void* samples, ClipInfo* info, c
                            const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
                            float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu) {
   const int waves = frames3d_waves(ft);
-#define AFX_F3D_GO(FMT, W)                                                                                                    \
-  (spec ? launch_frames3d_t<FMT, W, true>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu) \
-        : launch_frames3d_t<FMT, W, false>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu))
+  // the compiled-in schedule: rounds of width 1 with 1, 1, 2, 4 batches, every lane an owner, weights packed round after round
+  bool fixed = ft.mel_rounds == 4 && ft.mel_all_own && !dev_env().f3_generic_mel;
+  const int want_nb[4] = {1, 1, 2, 4};
+  int woff = 0;
+  for (int r = 0; r < 4 && fixed; ++r) {
+    fixed = (int)(ft.mel_rp[r] & 15) == want_nb[r] && ((ft.mel_rp[r] >> 4) & 15) == 1 && (int)(ft.mel_rp[r] >> 8) == woff;
+    woff += want_nb[r] * 256;
+  }
+#define AFX_F3D_GO2(FMT, W, NBS)                                                                                                    \
+  (spec ? launch_frames3d_t<FMT, W, true, NBS>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu) \
+        : launch_frames3d_t<FMT, W, false, NBS>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu))
+#define AFX_F3D_GO(FMT, W) (fixed ? AFX_F3D_GO2(FMT, W, 0x4211) : AFX_F3D_GO2(FMT, W, 0))
   if (kp.fmt == AFX_FMT_S16) return waves == 16 ? AFX_F3D_GO(AFX_FMT_S16, 16) : AFX_F3D_GO(AFX_FMT_S16, 12);
   return waves == 16 ? AFX_F3D_GO(AFX_FMT_F32, 16) : AFX_F3D_GO(AFX_FMT_F32, 12);
 #undef AFX_F3D_GO
+#undef AFX_F3D_GO2
 }
 
 }  // namespace afx

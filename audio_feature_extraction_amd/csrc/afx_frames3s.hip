@@ -36,7 +36,10 @@ size_t frames3s_lds_bytes(int waves, const F3Tables& ft) {
 // spectral_centroid, spectral_bandwidth (p = 2, normalised), spectral_rolloff (85 %), and per octave band of
 // spectral_contrast the mean of the `cnt` largest and smallest magnitudes (peak / valley; the dB difference and its
 // clip-global top_db clamp are taken on the host).  17 floats per frame at desc_out[desc_offs[clip] + 17 t].
-template <int FMT, int WAVES, bool SPEC, bool DESC>
+// NBS > 0: the mel schedule is known at compile time -- the batch counts (NBS) and lanes per filter (WDS) of up to four rounds
+// as nibbles, first round lowest (the reference's 44.1 kHz / 128 mels plans batches 3, 1, 5, 5 at widths 1, 4, 2, 4:
+// NBS 0x5513, WDS 0x4241) -- and is walked as straight-line code.  NBS = 0: any schedule, batches behind uniform branches.
+template <int FMT, int WAVES, bool SPEC, bool DESC, int NBS = 0, int WDS = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict__ samples,
                                                          ClipInfo* __restrict__ info,
                                                          const BlockDesc* __restrict__ blocks, int nblocks,
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
       // ---- 1024-point complex FFT (k_frames3's schedule)
       f3_dft16(z, H, W1, W3);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) e1w[k] = z[k];
+      for (int k = 0; k < 16; ++k) stv(e1w + k, z[k]);       // unmerged 8-byte stores: 2 x 6 LDS cycles against 13 for ds_write2_b64
 #pragma unroll
       for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 68 * u);
       {
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
         for (int r = 1; r < 8; ++r) cmul2(xa[r], tw[r], xb[r], tw[r]);
         f3_dft8(xa, H); f3_dft8(xb, H);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { e2w[16 * r] = xa[r]; e2w[16 * r + 512] = xb[r]; }
+        for (int r = 0; r < 8; ++r) { stv(e2w + 16 * r, xa[r]); stv(e2w + 16 * r + 512, xb[r]); }
       }
       v2 A[8], B[8];
 #pragma unroll
@@ -353,6 +356,39 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
       // ---- mel + dB: a lane walks 4 * nb consecutive bins of its filter, four per 16-byte read
       const bool vF = f < Tleft;
       float* const rowF = tile + (unsigned)(f * M);
+      __builtin_amdgcn_s_setprio(1);          // a wave in its mel phase (LDS reads) goes ahead of its SIMD mates' FFTs: k_frames3
+      if constexpr (NBS > 0) {
+        int woff = 0;
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+          constexpr int kNbs = NBS, kWds = WDS;
+          const int nb = (kNbs >> (4 * rd)) & 15, wd = (kWds >> (4 * rd)) & 15;
+          if (nb == 0) break;
+          const int meta = MM[rd * 64 + lane];
+          const float4* pp = reinterpret_cast<const float4*>(XB + (meta & 2047));
+          const float4* ww = reinterpret_cast<const float4*>(MW + woff) + lane;
+          woff += nb * 256;
+          v2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (i < nb) {
+              const float4 c = ww[64 * i], q = pp[i];
+              if (i == 0) { a0 = v2{q.x, q.y} * v2{c.x, c.y}; a1 = v2{q.z, q.w} * v2{c.z, c.w}; }
+              else { a0 = v2{q.x, q.y} * v2{c.x, c.y} + a0; a1 = v2{q.z, q.w} * v2{c.z, c.w} + a1; }
+            }
+          }
+          const v2 a = a0 + a1;
+          float acc = a.x + a.y;
+          if (wd >= 2) acc += F3_DPP(acc, 0xB1);
+          if (wd >= 4) acc += F3_DPP(acc, 0x4E);
+          if (wd >= 8) acc += F3_DPP(acc, 0x141);
+          const float L = 3.01029995663981195f * __builtin_amdgcn_logf(f3_max(acc, amin));
+          if (wd == 1 || (meta & (1 << 20))) {              // width 1: every lane owns its filter (launch_frames3s checks)
+            const unsigned m = (meta >> 11) & 511;
+            if (vF) { rowF[m] = L; lmax = f3_max(lmax, L); }
+          }
+        }
+      } else {
 #pragma unroll 1
       for (int rd = 0; rd < n_rounds; ++rd) {
         const uint32_t rp = ft.mel_rp[rd];
@@ -380,6 +416,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
           if (vF) { rowF[m] = L; lmax = f3_max(lmax, L); }
         }
       }
+      }
+      __builtin_amdgcn_s_setprio(0);
       }
 
       // ---- take in the next frame's 4 new rows (sub-block t0 + f + 2 of the clip)
@@ -425,7 +463,7 @@ int frames3s_waves(const F3Tables& ft) {
   return frames3s_lds_bytes(16, ft) <= 160 * 1024 ? 16 : 12;
 }
 
-template <int FMT, int WAVES, bool SPEC>
+template <int FMT, int WAVES, bool SPEC, int NBS, int WDS>
 static hipError_t launch_frames3s_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
                                     int nblocks, const int* nblocks_dev, const F3Tables& ft, const KParams& kp,
                                     float* logmel, float* blockmax, float* bsum, int* work_ctr, int n_cu) {
@@ -434,13 +472,13 @@ static hipError_t launch_frames3s_t(hipStream_t s, const void* samples, ClipInfo
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3s<FMT, WAVES, SPEC, false>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frames3s<FMT, WAVES, SPEC, false, NBS, WDS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
   const int grid = std::max(1, std::min(n_cu, (nblocks + WAVES - 1) / WAVES));
-  hipLaunchKernelGGL((k_frames3s<FMT, WAVES, SPEC, false>), dim3(grid), dim3(WAVES * 64), frames3s_lds_bytes(WAVES, ft), s,
+  hipLaunchKernelGGL((k_frames3s<FMT, WAVES, SPEC, false, NBS, WDS>), dim3(grid), dim3(WAVES * 64), frames3s_lds_bytes(WAVES, ft), s,
                      samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, nullptr, nullptr, SpecBands{}, work_ctr);
   return hipGetLastError();
 }
@@ -476,12 +514,24 @@ hipError_t launch_frames3s(hipStream_t s, const void* samples, ClipInfo* info, c
                            const int* nblocks_dev, const F3Tables& ft, const KParams& kp, float* logmel,
                            float* blockmax, float* bsum, bool spec, int* work_ctr, int n_cu) {
   const int waves = frames3s_waves(ft);
-#define AFX_F3S_GO(FMT, W)                                                                                                    \
-  (spec ? launch_frames3s_t<FMT, W, true>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu) \
-        : launch_frames3s_t<FMT, W, false>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu))
+  // the compiled-in schedule: batches 3, 1, 5, 5 at widths 1, 4, 2, 4, weights packed round after round; in a width-1 round
+  // every lane must own a filter (the straight-line code stores without an owner test there)
+  bool fixed = ft.mel_rounds == 4 && !dev_env().f3_generic_mel;
+  const int want_nb[4] = {3, 1, 5, 5}, want_wd[4] = {1, 4, 2, 4};
+  int woff = 0;
+  for (int r = 0; r < 4 && fixed; ++r) {
+    fixed = (int)(ft.mel_rp[r] & 15) == want_nb[r] && (int)((ft.mel_rp[r] >> 4) & 15) == want_wd[r] && (int)(ft.mel_rp[r] >> 8) == woff;
+    woff += want_nb[r] * 256;
+  }
+  fixed = fixed && (ft.mel_own_w1 != 0);
+#define AFX_F3S_GO2(FMT, W, NBS, WDS)                                                                                                    \
+  (spec ? launch_frames3s_t<FMT, W, true, NBS, WDS>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu) \
+        : launch_frames3s_t<FMT, W, false, NBS, WDS>(s, samples, info, blocks, nblocks, nblocks_dev, ft, kp, logmel, blockmax, bsum, work_ctr, n_cu))
+#define AFX_F3S_GO(FMT, W) (fixed ? AFX_F3S_GO2(FMT, W, 0x5513, 0x4241) : AFX_F3S_GO2(FMT, W, 0, 0))
   if (kp.fmt == AFX_FMT_S16) return waves == 16 ? AFX_F3S_GO(AFX_FMT_S16, 16) : AFX_F3S_GO(AFX_FMT_S16, 12);
   return waves == 16 ? AFX_F3S_GO(AFX_FMT_F32, 16) : AFX_F3S_GO(AFX_FMT_F32, 12);
 #undef AFX_F3S_GO
+#undef AFX_F3S_GO2
 }
 
 }  // namespace afx
