@@ -299,6 +299,21 @@ extern "C" int afx_plan_create(afx_ctx* ctx, const afx_params* p, afx_plan** out
   kp.rms_sub = (pl->use_f3 || frames2_eligible(kp, pl->dt)) ? kp.trim_hop / kp.hop : 0;
   pl->dt.n_cgroups = t.dctb.n_cgroups;
   if (t.dctb.P.size() < 64) pl->dt.dctP = nullptr;
+  pl->dt.dctS = nullptr;
+  if (p->n_mels % 32 == 0 && p->n_mels <= 128 && p->n_mfcc > 16 && p->n_mfcc <= 48) {
+    // A images of the folded DCT (k_tail<., true>): [(g KS + s) 4 + c][lane (i, q)] = dct[coef(g, i)][16 s + 4 q + c], the even
+    // coefficients in the first GH groups, the odd ones in the rest; rows beyond n_mfcc are zero
+    const int M = p->n_mels, K = p->n_mfcc, KS = M / 32, GH = ((K + 1) / 2 + 15) / 16, NG = 2 * GH;
+    std::vector<float> S((size_t)NG * KS * 4 * 64, 0.f);
+    for (int g = 0; g < NG; ++g)
+      for (int s = 0; s < KS; ++s)
+        for (int c = 0; c < 4; ++c)
+          for (int l = 0; l < 64; ++l) {
+            const int i = l & 15, q = l >> 4, k = 2 * (16 * (g % GH) + i) + g / GH, m = 16 * s + 4 * q + c;
+            if (k < K) S[(((size_t)g * KS + s) * 4 + c) * 64 + l] = t.dct[(size_t)k * M + m];
+          }
+    if ((rc = upload(pl, S.data(), S.size(), &pl->dt.dctS)) != AFX_OK) { afx_plan_destroy(pl); return rc; }
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
     pl->n_cu = prop.multiProcessorCount;
@@ -621,7 +636,7 @@ static int chunk_enqueue(afx_plan* pl, const void* samples, int fmt, int mem_kin
   const size_t info_at = (stats_bytes + 15) & ~(size_t)15;
   if (fused_tail)
     TIMED(AFX_K_DCT, launch_tail(s, d_clips, d_info, pl->dt, kp, (const float*)pl->logmel.p, (const float*)pl->rms.p,
-                                 (float*)pl->h_pin_dev, (ClipInfo*)((char*)pl->h_pin_dev + info_at), n, tail_spec));
+                                 (float*)pl->h_pin_dev, (ClipInfo*)((char*)pl->h_pin_dev + info_at), n, tail_spec, pl->n_cu));
   else
   TIMED(AFX_K_STATS, launch_stats(s, d_clips, d_info, kp, (const float*)pl->mfcc.p, (const float*)pl->rms.p,
                                   (float*)pl->h_pin_dev, d_frames, (const int64_t*)pl->frame_offs.p, n,

@@ -62,6 +62,7 @@ struct DevTables {
   int32_t mel_ntaps;      // floats in mel_taps; 0: tables unusable, generic kernel
   const float* dctA;     // DCT-II rows as MFMA A images
   const float* dctP;     // the same, permuted for k_dct16's 16-byte tile loads (nullptr: not applicable)
+  const float* dctS;     // k_tail<., SYM>: A images of the folded contraction -- even coefficients' groups, then odd ones' (nullptr: n/a)
   int32_t n_groups;      // ceil(n_mels / 16)
   int32_t n_cgroups;     // ceil(n_mfcc / 16)
 };
@@ -106,6 +107,7 @@ hipError_t launch_preemph(hipStream_t s, const float* y, float* out, int64_t n, 
 // frame kernels; the MFCC rows are never written.  Replaces launch_dct + launch_stats when no per-frame output is wanted.
 bool tail_eligible(const KParams& kp, const DevTables& tb);
 hipError_t launch_tail(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb, const KParams& kp,
-                       const float* logmel, const float* rms_rows, float* stats, ClipInfo* info_out, int n_clips, int spec);
+                       const float* logmel, const float* rms_rows, float* stats, ClipInfo* info_out, int n_clips, int spec,
+                       int n_cu);
 
 }  // namespace afx

@@ -16,6 +16,7 @@
 // read once at HBM rate; nothing else moves.  Per-frame export (out_frames) keeps the two-kernel path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 
 #include "afx_device.h"
@@ -28,11 +29,22 @@ __device__ __forceinline__ float tl_ord2f(uint32_t o) {
   const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
   return __uint_as_float(u);
 }
-// sum over the 16 lanes of a row (all lanes of the row end with the total); doubles go as two dwords through DPP-free
-// shuffles: this runs once per clip, not per tile
+// sum over the 16 lanes of a row (all lanes of the row end with the total).  The two dwords of a double go through DPP moves
+// (__shfl_xor lowers to ds_bpermute round trips: 24 sums x 4 steps of those were 10 us per clip and wave)
+#define TL_DPP(x, ctrl) __builtin_amdgcn_update_dpp(0, (x), (ctrl), 0xf, 0xf, false)
+__device__ __forceinline__ double tl_dpp_d(double v, const int ctrl_sel) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)b, hi = (int)(b >> 32);
+  switch (ctrl_sel) {
+    case 0: lo = TL_DPP(lo, 0xB1); hi = TL_DPP(hi, 0xB1); break;       // quad_perm [1,0,3,2]
+    case 1: lo = TL_DPP(lo, 0x4E); hi = TL_DPP(hi, 0x4E); break;       // quad_perm [2,3,0,1]
+    case 2: lo = TL_DPP(lo, 0x141); hi = TL_DPP(hi, 0x141); break;     // row_half_mirror
+    default: lo = TL_DPP(lo, 0x140); hi = TL_DPP(hi, 0x140); break;    // row_mirror
+  }
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double tl_row_sum(double v) {
-#pragma unroll
-  for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  v += tl_dpp_d(v, 0); v += tl_dpp_d(v, 1); v += tl_dpp_d(v, 2); v += tl_dpp_d(v, 3);
   return v;
 }
 __device__ __forceinline__ double tl_wave_sum(double v) {
@@ -43,22 +55,37 @@ __device__ __forceinline__ double tl_wave_sum(double v) {
 
 constexpr int kTailWaves = 4;
 
-template <int NCG>
+// SYM: the DCT-II rows are symmetric (even k) or antisymmetric (odd k) about the middle of the mel axis,
+// d_k(M - 1 - m) = (-1)^k d_k(m), so the contraction folds to M / 2 terms over L_m + L_{M-1-m} (even rows) or L_m - L_{M-1-m}
+// (odd rows): NG = 2 GH row groups -- GH of even coefficients, then GH of odd ones -- at half the k-steps each.  For 17..32 /
+// 33..48 coefficients that is 32 / 64 MFMAs per 16-frame tile instead of 64 / 96 (the kernel is bound by the matrix pipe
+// there, not by the spill's bytes).  Lane (f, q) then also fetches the mirrored filters 16 (S - 1 - s) + 4 (3 - q) + {3..0}.
+// Plain (SYM = false): NG = ceil(K / 16) groups of consecutive coefficients over all M terms.
+template <int NG, bool SYM>
 __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __restrict__ clips,
                                                           const ClipInfo* __restrict__ info,
                                                           const float* __restrict__ dctP, KParams kp,
                                                           const float* __restrict__ logmel,
                                                           const float* __restrict__ rms_rows,
                                                           float* __restrict__ stats,
-                                                          ClipInfo* __restrict__ info_out, int spec) {
+                                                          ClipInfo* __restrict__ info_out, int spec, int n_clips) {
   extern __shared__ float tl_smem[];
+  constexpr int NCG = NG;                                  // rows of coefficients handled: 16 NG
+  constexpr int GH = SYM ? NG / 2 : NG;
   const int M = kp.n_mels, K = kp.n_mfcc, S = M >> 4;     // S <= 8
-  float* const dct_tab = tl_smem;                          // [(g S + s) 4 + c][64 lanes]
-  float* const edge = dct_tab + NCG * S * 4 * 64;          // [k < 16 NCG][18]: frames 0..8, T-9..T-1 of row k
+  const int KS = SYM ? S >> 1 : S;                         // 16-filter segments the contraction runs over
+  float* const dct_tab = tl_smem;                          // [(g KS + s) 4 + c][64 lanes]
+  float* const edge = dct_tab + NCG * KS * 4 * 64;         // [k < 16 NG][18]: frames 0..8, T-9..T-1 of row k
   double* const part = reinterpret_cast<double*>(edge + NCG * 16 * 18 + (((NCG * 16 * 18) & 1) ? 1 : 0));   // [wave][k][2]
   double* const red = part + kTailWaves * NCG * 16 * 2;   // block reductions of the RMS row: [wave][4]
-  const int clip = blockIdx.x;
+  // coefficient of row i of group g: consecutive, or (SYM) even coefficients in the first GH groups, odd ones in the rest
+  auto coef = [&](int g, int i) -> int { return SYM ? 2 * (16 * (g % GH) + i) + g / GH : 16 * g + i; };
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // a workgroup walks clips blockIdx.x, + gridDim.x, ...: the DCT images are copied to LDS once per workgroup, not per clip
+  for (int i = tid * 4; i < NCG * KS * 4 * 64; i += kTailWaves * 64 * 4)
+    *reinterpret_cast<float4*>(dct_tab + i) = *reinterpret_cast<const float4*>(dctP + i);
+  for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
+  __syncthreads();                                         // the previous clip's readers of edge / part / red are done (and the table is there)
   const ClipInfo ci = info[clip];
   const ClipDesc cd = clips[clip];
   if (info_out && tid == 0) info_out[clip] = ci;           // the caller's copy (host memory the device can write)
@@ -68,14 +95,12 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
   const bool energy_only = ci.status == AFX_CLIP_TOO_SHORT && cd.len >= 2 && ci.T >= 1;
   if (ci.status != AFX_CLIP_OK) {                          // uniform per workgroup
     for (int i = tid; i < 4 * K + (energy_only ? 0 : 3); i += kTailWaves * 64) st[i] = 0.f;
-    if (!energy_only) return;
+    if (!energy_only) continue;
   }
   const int T = ci.T;
   const double invT = 1.0 / (double)T;
 
   if (ci.status == AFX_CLIP_OK) {
-    for (int i = tid; i < NCG * S * 4 * 64; i += kTailWaves * 64) dct_tab[i] = dctP[i];
-    __syncthreads();
     const float theta = tl_ord2f(ci.lmax_ord) - kp.top_db;
     const int f = lane & 15, q = lane >> 4;
     const int ntiles = (T + 15) >> 4;
@@ -84,25 +109,51 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
     // frame-major spill [frame][mel]: lane (f, q) fetches filters 16 s + 4 q + {0..3} of frame f with one 16-byte load
     // (a wave-load is a run of whole 64-byte pieces of 16 rows); rows past the clip's last frame are read but never used
     // (the spill is allocated 16 frames beyond the batch's last row)
-    auto load_tile = [&](int tile, float4 (&x)[8]) {
-      const float* src = logmel + (cd.frame_base + g0 + tile * 16 + f) * (int64_t)M + q * 4;
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-        x[s] = (s < S && tile < ntiles) ? *reinterpret_cast<const float4*>(src + s * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // One 16-filter segment of a tile: x[s] = filters 16 s + 4 q + {0..3} of frame f; SYM also x[4 + s] = their mirrors
+    // 16 (S - 1 - s) + 4 (3 - q) + {0..3}.  A segment's registers are refilled with the NEXT tile's values as soon as its
+    // MFMAs have read them -- the prefetch buffer is the operand buffer (a second one would cost 32 registers and, for 33..48
+    // coefficients, the second wave per SIMD).
+    auto load_seg = [&](int tile, int s, float4 (&x)[8]) {
+      const bool on = tile < ntiles;
+      const float* row = logmel + (cd.frame_base + g0 + tile * 16 + f) * (int64_t)M;
+      x[s] = on ? *reinterpret_cast<const float4*>(row + q * 4 + s * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (SYM) x[4 + s] = on ? *reinterpret_cast<const float4*>(row + (3 - q) * 4 + (S - 1 - s) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     double sm[NCG][4], sq[NCG][4];
 #pragma unroll
     for (int g = 0; g < NCG; ++g)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { sm[g][r] = 0.0; sq[g][r] = 0.0; }
-    float4 xc[8], xn[8];
+    float4 xc[8];
     int tile = wave;
-    load_tile(tile, xc);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) if (s < KS) load_seg(tile, s, xc);
     for (; tile < ntiles; tile += kTailWaves) {
-      load_tile(tile + kTailWaves, xn);
       tl_f32x4 acc[NCG][2];
 #pragma unroll
       for (int g = 0; g < NCG; ++g) { acc[g][0] = tl_f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = tl_f32x4{0.f, 0.f, 0.f, 0.f}; }
+      if constexpr (SYM) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (s < KS) {
+            // clamp first (power_to_db's top_db), then fold: filter m with its mirror M - 1 - m (component c with 3 - c)
+            const float u0 = fmaxf(xc[s].x, theta), u1 = fmaxf(xc[s].y, theta), u2 = fmaxf(xc[s].z, theta), u3 = fmaxf(xc[s].w, theta);
+            const float w0 = fmaxf(xc[4 + s].w, theta), w1 = fmaxf(xc[4 + s].z, theta), w2 = fmaxf(xc[4 + s].y, theta), w3 = fmaxf(xc[4 + s].x, theta);
+            const float e0 = u0 + w0, e1 = u1 + w1, e2 = u2 + w2, e3 = u3 + w3;
+            const float o0 = u0 - w0, o1 = u1 - w1, o2 = u2 - w2, o3 = u3 - w3;
+#pragma unroll
+            for (int g = 0; g < NCG; ++g) {
+              const float* a = dct_tab + ((g * KS + s) * 4) * 64 + lane;
+              const bool ev = g < GH;
+              acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], ev ? e0 : o0, acc[g][0], 0, 0, 0);
+              acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[64], ev ? e1 : o1, acc[g][1], 0, 0, 0);
+              acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[128], ev ? e2 : o2, acc[g][0], 0, 0, 0);
+              acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[192], ev ? e3 : o3, acc[g][1], 0, 0, 0);
+            }
+            load_seg(tile + kTailWaves, s, xc);
+          }
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         if (s < S) {
@@ -116,7 +167,9 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
             acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[128], b2, acc[g][0], 0, 0, 0);
             acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[192], b3, acc[g][1], 0, 0, 0);
           }
+          load_seg(tile + kTailWaves, s, xc);
         }
+      }
       }
       const int t = tile * 16 + f;
       const bool live = t < T;
@@ -132,14 +185,12 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
         if (edge_tile && live) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int k = g * 16 + q * 4 + r;
+            const int k = coef(g, q * 4 + r);
             if (t < 9) edge[k * 18 + t] = r4[r];
             if (t >= T - 9) edge[k * 18 + 9 + (t - (T - 9))] = r4[r];
           }
         }
       }
-#pragma unroll
-      for (int s = 0; s < 8; ++s) xc[s] = xn[s];
     }
     // ---- per wave: totals of the 16 frame lanes of each coefficient row
 #pragma unroll
@@ -148,7 +199,7 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
       for (int r = 0; r < 4; ++r) {
         const double a = tl_row_sum(sm[g][r]), b = tl_row_sum(sq[g][r]);
         if (f == 0) {
-          const int k = g * 16 + q * 4 + r;
+          const int k = coef(g, q * 4 + r);
           part[(wave * NCG * 16 + k) * 2] = a;
           part[(wave * NCG * 16 + k) * 2 + 1] = b;
         }
@@ -238,29 +289,56 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
       st[4 * K + 2] = (float)gmx - (float)gmn;
     }
   }
+  }
 }
 
 bool tail_eligible(const KParams& kp, const DevTables& tb) {
   return tb.dctP != nullptr && kp.n_mels % 16 == 0 && kp.n_mels <= 128 && kp.n_mfcc <= 48;
 }
 
-size_t tail_lds_bytes(int ncg, int n_mels) {
-  const size_t tab = (size_t)ncg * (n_mels / 16) * 4 * 64, edge = (size_t)ncg * 16 * 18 + 1;
-  return (tab + edge) * sizeof(float) + ((size_t)kTailWaves * ncg * 16 * 2 + kTailWaves * 4) * sizeof(double) + 16;
+// the folded contraction pays when it needs fewer row groups per k-step pair: GH = ceil(ceil(K / 2) / 16) < ceil(K / 16)
+int tail_sym_groups(const KParams& kp, const DevTables& tb) {
+  if (!tb.dctS || kp.n_mels % 32 != 0) return 0;
+  const int gh = ((kp.n_mfcc + 1) / 2 + 15) / 16, ncg = (kp.n_mfcc + 15) / 16;
+  return gh < ncg ? gh : 0;
+}
+
+static size_t tail_lds_bytes(int ng, int ks) {
+  const size_t tab = (size_t)ng * ks * 4 * 64, edge = (size_t)ng * 16 * 18 + 1;
+  return (tab + edge) * sizeof(float) + ((size_t)kTailWaves * ng * 16 * 2 + kTailWaves * 4) * sizeof(double) + 16;
+}
+
+template <int NG, bool SYM>
+static hipError_t launch_tail_t(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const float* table, const KParams& kp,
+                                const float* logmel, const float* rms_rows, float* stats, ClipInfo* info_out, int n_clips,
+                                int spec, int n_cu) {
+  const size_t lds = tail_lds_bytes(NG, SYM ? kp.n_mels / 32 : kp.n_mels / 16);
+  // as many workgroups as the chip holds at once (asked of the runtime once per instantiation), each walking its share of the clips
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_tail<NG, SYM>), kTailWaves * 64, lds) != hipSuccess || nb < 1) nb = 2;
+    per_cu = std::min(nb, 8);
+  }
+  dim3 grid(std::max(1, std::min(n_clips, n_cu * per_cu))), block(kTailWaves * 64);
+  hipLaunchKernelGGL((k_tail<NG, SYM>), grid, block, lds, s, clips, info, table, kp, logmel, rms_rows, stats, info_out, spec, n_clips);
+  return hipGetLastError();
 }
 
 hipError_t launch_tail(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const DevTables& tb, const KParams& kp,
-                       const float* logmel, const float* rms_rows, float* stats, ClipInfo* info_out, int n_clips, int spec) {
-  const int ncg = (kp.n_mfcc + 15) / 16;
-  const size_t lds = tail_lds_bytes(ncg, kp.n_mels);
-  dim3 grid(n_clips), block(kTailWaves * 64);
-  switch (ncg) {
-    case 1: hipLaunchKernelGGL((k_tail<1>), grid, block, lds, s, clips, info, tb.dctP, kp, logmel, rms_rows, stats, info_out, spec); break;
-    case 2: hipLaunchKernelGGL((k_tail<2>), grid, block, lds, s, clips, info, tb.dctP, kp, logmel, rms_rows, stats, info_out, spec); break;
-    case 3: hipLaunchKernelGGL((k_tail<3>), grid, block, lds, s, clips, info, tb.dctP, kp, logmel, rms_rows, stats, info_out, spec); break;
+                       const float* logmel, const float* rms_rows, float* stats, ClipInfo* info_out, int n_clips, int spec,
+                       int n_cu) {
+  const int gh = tail_sym_groups(kp, tb);
+#define AFX_TAIL(NG, SYM, TAB) launch_tail_t<NG, SYM>(s, clips, info, TAB, kp, logmel, rms_rows, stats, info_out, n_clips, spec, n_cu)
+  if (gh == 1) return AFX_TAIL(2, true, tb.dctS);
+  if (gh == 2) return AFX_TAIL(4, true, tb.dctS);
+  switch ((kp.n_mfcc + 15) / 16) {
+    case 1: return AFX_TAIL(1, false, tb.dctP);
+    case 2: return AFX_TAIL(2, false, tb.dctP);
+    case 3: return AFX_TAIL(3, false, tb.dctP);
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
+#undef AFX_TAIL
 }
 
 }  // namespace afx

@@ -187,7 +187,10 @@ def test_fused_tail_equals_the_two_kernel_tail(sr, n_fft, hop, n_mfcc):
     for i in range(len(clips)):
         a, b = one["stats"][i].astype(np.float64), two["stats"][i].astype(np.float64)
         if one["status"][i] == 0:
-            scale = np.maximum(np.abs(b), 1e-3 * np.abs(b[:K]).max())
+            # each value on its own scale, floored at 1e-2 of the clip's largest coefficient mean: a row that is
+            # numerically zero (digital silence: every coefficient but c0) is rounding noise of the c0-sized terms it
+            # cancels, and the folded DCT (L_m - L_{M-1-m} for odd rows) cancels them exactly where the full one does not
+            scale = np.maximum(np.abs(b), 1e-2 * np.abs(b[:K]).max())
             assert (np.abs(a - b) <= 2e-6 * scale).all(), (i, np.abs(a - b).max())
             if i % 4 == 0 or i in (3, 4):
                 check_stats(one["stats"][i], oracle_stats(clips[i], sr, n_fft, hop, K), K, f"fused tail clip {i}")
