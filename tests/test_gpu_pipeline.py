@@ -159,7 +159,8 @@ def test_distinct_ragged_batches_through_two_plans(sr, n_fft, hop, n_mfcc):
 def test_fused_tail_equals_the_two_kernel_tail(sr, n_fft, hop, n_mfcc):
     """k_tail (clamp + DCT + statistics per clip, MFCC rows never written; what a statistics-only batch runs) against the
     k_dct16* + k_stats pair that a batch with per-frame output still runs: same statuses, trims and frame counts, and the
-    statistics equal up to the order of the float64 row sums; and both against the oracle.  Clips: ordinary, silence-padded
+    statistics equal to a few float32 ulps of the values they are formed from (tolerance 2e-5 on each value's own scale; the
+    parity gate proper is the oracle check, 1e-4).  Clips: ordinary, silence-padded
     (a real trim, frame offset > 0), 9 and 10 frames (the delta's minimum), fewer than 9 (energy only), non-finite."""
     from tests.parity import check_stats, oracle_stats
     clips = [make_clip(400 + i, sr, 0.6 + 0.21 * (i % 7), speechy=(i % 3 == 0)) for i in range(37)]
@@ -191,7 +192,9 @@ def test_fused_tail_equals_the_two_kernel_tail(sr, n_fft, hop, n_mfcc):
             # numerically zero (digital silence: every coefficient but c0) is rounding noise of the c0-sized terms it
             # cancels, and the folded DCT (L_m - L_{M-1-m} for odd rows) cancels them exactly where the full one does not
             scale = np.maximum(np.abs(b), 1e-2 * np.abs(b[:K]).max())
-            assert (np.abs(a - b) <= 2e-6 * scale).all(), (i, np.abs(a - b).max())
+            # 2e-5: the two tails round the MFCC values differently in the last bit (row sums in another order, the folded
+            # contraction), and a delta mean of a ten-frame clip is a difference of such values divided by ten
+            assert (np.abs(a - b) <= 2e-5 * scale).all(), (i, np.abs(a - b).max())
             if i % 4 == 0 or i in (3, 4):
                 check_stats(one["stats"][i], oracle_stats(clips[i], sr, n_fft, hop, K), K, f"fused tail clip {i}")
         else:
