@@ -25,7 +25,7 @@ K_FRAMES = 2
 # every symbol include/afx.h declares
 SYMBOLS = (
     "afx_version", "afx_device_count", "afx_last_error", "afx_init", "afx_destroy",
-    "afx_malloc", "afx_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
+    "afx_malloc", "afx_free", "afx_host_alloc", "afx_host_free", "afx_memcpy_h2d", "afx_memcpy_d2h", "afx_synchronize",
     "afx_default_params", "afx_plan_create", "afx_plan_destroy", "afx_build_tables", "afx_build_mel_schedule",
     "afx_extract_batch", "afx_extract_submit", "afx_extract_collect", "afx_f0_batch", "afx_zcr_batch", "afx_spectral_batch", "afx_f0_build_tables", "afx_preprocess", "afx_plan_set_timing", "afx_plan_get_timings", "afx_plan_get_intervals",
     "afx_wav_probe", "afx_wav_read_s16", "afx_batch_geometry",
@@ -72,6 +72,8 @@ def lib() -> C.CDLL:
         L.afx_destroy.argtypes = [vp]; L.afx_destroy.restype = None
         L.afx_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         L.afx_free.argtypes = [vp, vp]
+        L.afx_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.afx_host_free.argtypes = [vp, vp]
         L.afx_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
         L.afx_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
         L.afx_synchronize.argtypes = [vp]
@@ -238,6 +240,36 @@ class DeviceBuffer:
             pass
 
 
+class PinnedBuffer:
+    """Page-locked host memory owned by a Context: ``array(dtype, count)`` is a numpy view of its start.  Uploads from it
+    are DMA at link rate (no staging copy by the runtime)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        ptr = C.c_void_p()
+        _check(lib().afx_host_alloc(ctx.handle, self.nbytes, C.byref(ptr)), "afx_host_alloc")
+        self.ptr = ptr.value
+        self._raw = (C.c_char * max(self.nbytes, 1)).from_address(self.ptr)
+
+    def array(self, dtype, count: int) -> np.ndarray:
+        dt = np.dtype(dtype)
+        if count * dt.itemsize > self.nbytes:
+            raise ValueError("view larger than the pinned block")
+        return np.frombuffer(self._raw, dtype=dt, count=int(count))
+
+    def free(self):
+        if self.ptr:
+            self._raw = None
+            lib().afx_host_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Context:
     """One HIP device + stream.  Not thread-safe: one per worker thread."""
 
@@ -284,6 +316,10 @@ class Plan:
     def device_buffer(self, nbytes: int) -> "DeviceBuffer":
         """HBM allocation on this plan's device (the seam parallel.process_files uploads a window through)."""
         return DeviceBuffer(self.ctx, nbytes)
+
+    def pinned_buffer(self, nbytes: int) -> "PinnedBuffer":
+        """Page-locked host block on this plan's device context (what a window of files is packed into)."""
+        return PinnedBuffer(self.ctx, nbytes)
 
     def set_timing(self, on, frames_only: bool = False):
         """HIP events around every kernel of a batch (or, frames_only, around the frame kernel alone)."""

@@ -190,6 +190,22 @@ extern "C" int afx_free(afx_ctx* ctx, void* d) {
   return AFX_OK;
 }
 
+extern "C" int afx_host_alloc(afx_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out) { set_error("afx_host_alloc: null argument"); return AFX_ERR_INVALID; }
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);
+  if (e != hipSuccess) { set_error(std::string("hipHostMalloc: ") + hipGetErrorString(e)); *out = nullptr; return e == hipErrorOutOfMemory ? AFX_ERR_NOMEM : AFX_ERR_HIP; }
+  return AFX_OK;
+}
+
+extern "C" int afx_host_free(afx_ctx* ctx, void* h) {
+  if (!ctx) { set_error("afx_host_free: null ctx"); return AFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (h) HIP_TRY(hipHostFree(h));
+  return AFX_OK;
+}
+
 extern "C" int afx_memcpy_h2d(afx_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx || (!dst && bytes) || (!src && bytes)) { set_error("afx_memcpy_h2d: null argument"); return AFX_ERR_INVALID; }
   HIP_TRY(hipSetDevice(ctx->device));

@@ -19,6 +19,8 @@ int afx_init(int, afx_ctx** out) { if (out) *out = nullptr; return no_device("af
 void afx_destroy(afx_ctx*) {}
 int afx_malloc(afx_ctx*, size_t, void**) { return no_device("afx_malloc"); }
 int afx_free(afx_ctx*, void*) { return no_device("afx_free"); }
+int afx_host_alloc(afx_ctx*, size_t, void** out) { if (out) *out = nullptr; return no_device("afx_host_alloc"); }
+int afx_host_free(afx_ctx*, void*) { return no_device("afx_host_free"); }
 int afx_memcpy_h2d(afx_ctx*, void*, const void*, size_t) { return no_device("afx_memcpy_h2d"); }
 int afx_memcpy_d2h(afx_ctx*, void*, const void*, size_t) { return no_device("afx_memcpy_d2h"); }
 int afx_synchronize(afx_ctx*) { return no_device("afx_synchronize"); }

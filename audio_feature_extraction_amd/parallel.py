@@ -89,6 +89,28 @@ def _pack(clips: List[np.ndarray], dtype) -> Tuple[np.ndarray, np.ndarray, np.nd
     return buf, offsets, lengths
 
 
+class _PinPool:
+    """Page-locked window buffers of one (device, lane) worker, kept across windows and calls: the native reader fills
+    them, the upload is one DMA.  At most two are out at a time (window k on the device, k + 1 being read)."""
+
+    def __init__(self, plan):
+        self.plan, self.free, self.lock = plan, [], threading.Lock()
+
+    def get(self, nbytes: int):
+        with self.lock:
+            for i, b in enumerate(self.free):
+                if b.nbytes >= nbytes:
+                    return self.free.pop(i)
+            for b in self.free:                      # too small: give the memory back before taking more
+                b.free()
+            self.free.clear()
+        return self.plan.pinned_buffer(max(int(nbytes * 1.25), 1 << 20))
+
+    def put(self, b):
+        with self.lock:
+            self.free.append(b)
+
+
 LAST_TIMING: Dict[str, Any] = {}     # seconds per phase of the last process_files call (developer aid)
 WORKERS_PER_GPU = 3     # sub-batches in flight per GPU (own context / stream / thread): copies, the bandwidth-bound
                         # kernels and the host round trip of one hide under the frame kernel of another
@@ -193,10 +215,12 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
     native_threads = max(1, min(host_cpus, DECODE_THREADS_PER_GPU * len(devices)) // max(1, min(len(lanes), 4)))
     win_pool = ThreadPoolExecutor(max(1, len(lanes)))
 
-    def load_window(win):
-        """-> (packed 16-bit group or None, indices decoded by wavio, their decoded clips)"""
+    def load_window(win, pin=None):
+        """-> (packed 16-bit group or None, indices decoded by wavio, their decoded clips); pin: the worker's pool of
+        page-locked buffers (None: ordinary memory)"""
         rest = list(win)
         packed = None
+        held = None
         try:
             paths = [str(files[i]) for i in win]
             pr = _native.wav_probe(paths, native_threads)
@@ -208,17 +232,25 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
                 padded = (lens + 3) // 4 * 4                      # 4-element alignment, as _pack
                 offs = np.zeros(sel.size, np.int64)
                 offs[1:] = np.cumsum(padded)[:-1]
-                buf = np.empty(max(int(padded.sum()), 1), np.int16)
+                nel = max(int(padded.sum()), 1)
+                if pin is not None:
+                    held = pin.get(nel * 2)
+                    buf = held.array(np.int16, nel)
+                else:
+                    buf = np.empty(nel, np.int16)
                 st = _native.wav_read_s16([paths[j] for j in sel], pr["data_off"][sel], lens, buf, offs, native_threads)
                 for o, ln, pd in zip(offs[padded > lens], lens[padded > lens], padded[padded > lens]):
                     buf[o + ln: o + pd] = 0
                 good = st == 0
                 if good.any():
-                    packed = ([win[j] for j in sel[good]], buf, offs[good], lens[good])
+                    packed = ([win[j] for j in sel[good]], buf, offs[good], lens[good], held)
+                    held = None
                     taken = set(packed[0])
                     rest = [i for i in win if i not in taken]
         except Exception:                                         # no native reader: the Python decoder takes the window
             rest, packed = list(win), None
+        if held is not None:
+            pin.put(held)
         decoded = list(pool.map(dec, rest)) if rest else []
         return packed, rest, decoded
 
@@ -253,20 +285,27 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
 
     def worker(lane, idxs):
         wins = _windows(sizes, idxs, max_batch_samples)
-        pending = win_pool.submit(load_window, wins[0]) if wins else None
-        plan = None
+        plan = pin = None
+        try:                                                      # (MFCC / RMS plan, pYIN plan): own context and stream each
+            plan = (extractor._plan(lane[0], lane[1]),
+                    extractor._plan(lane[0], (lane[1], "f0")) if want_f0 else None)
+            if hasattr(plan[0], "pinned_buffer"):                 # page-locked window buffers, kept with the extractor
+                pools = extractor.__dict__.setdefault("_pin_pools", {})
+                pin = pools.get(lane) or pools.setdefault(lane, _PinPool(plan[0]))
+        except Exception as e:                                    # no device for this lane: its files are dropped, the batch goes on
+            for i in idxs:
+                errors[i] = e
+            return
+        pending = win_pool.submit(load_window, wins[0], pin) if wins else None
         for k, win in enumerate(wins):
             t0 = time.perf_counter()
             packed, rest, decoded = pending.result()
             # next window loads while this one is on the device
-            pending = win_pool.submit(load_window, wins[k + 1]) if k + 1 < len(wins) else None
+            pending = win_pool.submit(load_window, wins[k + 1], pin) if k + 1 < len(wins) else None
             t1 = time.perf_counter()
             try:
-                if plan is None:                                  # (MFCC / RMS plan, pYIN plan): own context and stream each
-                    plan = (extractor._plan(lane[0], lane[1]),
-                            extractor._plan(lane[0], (lane[1], "f0")) if want_f0 else None)
                 if packed is not None:                            # the natively packed 16-bit clips, in budget-sized runs
-                    ids, buf, offs, lens = packed
+                    ids, buf, offs, lens, _held = packed
                     pos = 0
                     while pos < len(ids):
                         tot, end = 0, pos
@@ -293,6 +332,8 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
                     if errors[i] is None and not (status[i] >= 0 and f0_done[i]):
                         errors[i] = e
                         status[i] = -1
+            if packed is not None and packed[4] is not None:
+                pin.put(packed[4])
             del decoded, packed
             with phase_lock:
                 phase["decode_wait"] += t1 - t0

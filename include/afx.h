@@ -98,6 +98,11 @@ void afx_destroy(afx_ctx* ctx);
 /* device memory helpers so that a binding needs no HIP API of its own */
 int afx_malloc(afx_ctx* ctx, size_t bytes, void** out_dptr);
 int afx_free(afx_ctx* ctx, void* dptr);
+/* Page-locked host memory for batch buffers that are uploaded (batch_process packs a window of decoded files into one,
+ * F:228-235): afx_memcpy_h2d from it is one DMA at link rate, from pageable memory the runtime stages it through its own
+ * pinned buffer first (a host copy at a fifth of that).  Free with afx_host_free before afx_destroy. */
+int afx_host_alloc(afx_ctx* ctx, size_t bytes, void** out);
+int afx_host_free(afx_ctx* ctx, void* hptr);
 int afx_memcpy_h2d(afx_ctx* ctx, void* dst_d, const void* src_h, size_t bytes);
 int afx_memcpy_d2h(afx_ctx* ctx, void* dst_h, const void* src_d, size_t bytes);
 int afx_synchronize(afx_ctx* ctx);
