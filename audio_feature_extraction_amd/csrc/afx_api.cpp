@@ -112,6 +112,7 @@ DevEnv::DevEnv() {
   host_blocks = getenv("AFX_HOST_BLOCKS") != nullptr;
   no_fused_tail = getenv("AFX_NO_FUSED_TAIL") != nullptr;
   if (const char* v = getenv("AFX_F3_WAVES")) f3_waves = atoi(v);
+  if (const char* v = getenv("AFX_TAIL_MODE")) tail_mode = atoi(v);
   if (const char* v = getenv("AFX_TEST_CHUNK_CLIPS")) chunk_clips = std::max(1, std::min(32768, atoi(v)));
   if (const char* v = getenv("AFX_TEST_F0_CHUNK_FRAMES")) f0_chunk_frames = std::max<int64_t>(64, atoll(v));
   f0_dump = getenv("AFX_F0_DUMP");

@@ -662,36 +662,33 @@ __global__ __launch_bounds__(256) void k_trim_decide3(const ClipDesc* __restrict
 // k_build_blocks3: the speculative launch's block list, built on the device from the batch's clip records.
 // reference call site: audio_feature_extraction_toolkit/core/feature_extractor.py:228-235 -- batch_process never sees the
 // same clip lengths twice, so nothing per batch may be built block by block on the host: the host uploads one 48-byte
-// ClipDesc per clip and this kernel writes the 64-byte record of every absolute 16-frame block (one thread per block,
-// the clip found by bisection of blk_base).  54 000 records (3.5 MB) for 1000 ten-second clips.
+// ClipDesc per clip and this kernel writes the 64-byte record of every absolute 16-frame block (one wave per clip).  54 000 records (3.5 MB) for 1000 ten-second clips.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_build_blocks3(const ClipDesc* __restrict__ clips, int n_clips, int nblocks,
-                                                       BlockDesc* __restrict__ blocks, int n_fft, int hop, int trim_hop, int per) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= nblocks) return;
-  int lo = 0, hi = n_clips - 1;                   // last clip with blk_base <= g (clips without blocks cannot occur: tpad >= 16)
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (clips[mid].blk_base <= g) lo = mid; else hi = mid - 1;
-  }
-  const ClipDesc c = clips[lo];
-  const int b = g - c.blk_base;
+__global__ __launch_bounds__(64) void k_build_blocks3(const ClipDesc* __restrict__ clips, int n_clips,
+                                                      BlockDesc* __restrict__ blocks, int n_fft, int hop, int trim_hop, int per) {
+  // one wave per clip: its record is read once (scalar), its blocks written lane by lane -- no search for the clip of a block
+  const int clip = blockIdx.x;
+  if (clip >= n_clips) return;
+  const ClipDesc c = clips[clip];
+  const int nb = c.tpad / kFramesPerBlock;
   const int64_t lim = (int64_t)1 << 30;
-  const int64_t gs = (int64_t)b * kFramesPerBlock * hop - n_fft / 2;       // clip sample of staged index 0
-  auto rel = [&](int64_t x) { const int64_t q = x - gs; return (int32_t)(q < -lim ? -lim : (q > lim ? lim : q)); };
   const int64_t ntb = (c.len + trim_hop - 1) / trim_hop;
-  BlockDesc d;
-  d.sample_base = c.off + gs; d.frame_slot = c.frame_base + (int64_t)b * kFramesPerBlock; d.clip_off = c.off;
-  d.keep_lo = rel(0); d.keep_hi = rel(c.len); d.have_lo = d.keep_lo; d.have_hi = d.keep_hi;
-  d.clip = lo; d.t0 = b * kFramesPerBlock; d.T = c.tmax; d.active = (c.len >= 2 && d.t0 < c.tmax) ? 1 : 0;
-  d.pad_[0] = (int32_t)(c.tblk_base * per); d.pad_[1] = (int32_t)(ntb * per);
-  blocks[g] = d;
+  for (int b = threadIdx.x; b < nb; b += 64) {
+    const int64_t gs = (int64_t)b * kFramesPerBlock * hop - n_fft / 2;       // clip sample of staged index 0
+    auto rel = [&](int64_t x) { const int64_t q = x - gs; return (int32_t)(q < -lim ? -lim : (q > lim ? lim : q)); };
+    BlockDesc d;
+    d.sample_base = c.off + gs; d.frame_slot = c.frame_base + (int64_t)b * kFramesPerBlock; d.clip_off = c.off;
+    d.keep_lo = rel(0); d.keep_hi = rel(c.len); d.have_lo = d.keep_lo; d.have_hi = d.keep_hi;
+    d.clip = clip; d.t0 = b * kFramesPerBlock; d.T = c.tmax; d.active = (c.len >= 2 && d.t0 < c.tmax) ? 1 : 0;
+    d.pad_[0] = (int32_t)(c.tblk_base * per); d.pad_[1] = (int32_t)(ntb * per);
+    blocks[c.blk_base + b] = d;
+  }
 }
 
 hipError_t launch_build_blocks3(hipStream_t s, const ClipDesc* clips, int n_clips, int nblocks, BlockDesc* blocks,
                                 const KParams& kp) {
   if (nblocks <= 0 || n_clips <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_build_blocks3, dim3((nblocks + 255) / 256), dim3(256), 0, s, clips, n_clips, nblocks, blocks,
+  hipLaunchKernelGGL(k_build_blocks3, dim3(n_clips), dim3(64), 0, s, clips, n_clips, blocks,
                      kp.n_fft, kp.hop, kp.trim_hop, kp.rms_sub);
   return hipGetLastError();
 }

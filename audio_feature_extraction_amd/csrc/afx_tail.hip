@@ -20,6 +20,7 @@
 #include <cmath>
 
 #include "afx_device.h"
+#include "afx_devenv.h"
 
 namespace afx {
 
@@ -53,7 +54,6 @@ __device__ __forceinline__ double tl_wave_sum(double v) {
   return v;
 }
 
-constexpr int kTailWaves = 4;
 
 // SYM: the DCT-II rows are symmetric (even k) or antisymmetric (odd k) about the middle of the mel axis,
 // d_k(M - 1 - m) = (-1)^k d_k(m), so the contraction folds to M / 2 terms over L_m + L_{M-1-m} (even rows) or L_m - L_{M-1-m}
@@ -61,8 +61,18 @@ constexpr int kTailWaves = 4;
 // 33..48 coefficients that is 32 / 64 MFMAs per 16-frame tile instead of 64 / 96 (the kernel is bound by the matrix pipe
 // there, not by the spill's bytes).  Lane (f, q) then also fetches the mirrored filters 16 (S - 1 - s) + 4 (3 - q) + {3..0}.
 // Plain (SYM = false): NG = ceil(K / 16) groups of consecutive coefficients over all M terms.
-template <int NG, bool SYM>
-__global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __restrict__ clips,
+//
+// RING > 0 (n_mels = 128 only): the tiles do not pass through registers on their way in.  A tile is 16 consecutive 512-byte
+// rows of the spill = 8 KB of contiguous memory; each wave keeps a ring of RING such tiles in LDS, filled by LDS-DMA
+// (global_load_lds_dwordx4: 8 wave-instructions of 1 KB per tile, no destination registers) RING - 1 tiles ahead, and reads
+// its MFMA operands from the ring with one ds_read_b128 per 16-filter segment.  Whole 128-byte lines are fetched (the
+// register path's loads are 16 rows x 64 bytes per instruction, half lines), and the bytes in flight no longer compete with
+// the float64 sums for registers -- with 33..48 coefficients the register path keeps ~4 KB per wave in flight at two waves
+// per SIMD and reads the spill at 2.9 TB/s.  The LDS image is lane-linear (the DMA's rule), so the bank swizzle is applied on
+// the SOURCE side: 16-byte chunk j of row f is stored at chunk position j ^ f of row f, and lane (f, q) reads chunk 4 s + q
+// of its row conflict-free.  RING = 0: the register path above (any n_mels that is a multiple of 16).
+template <int NG, bool SYM, int WAVES, int RING>
+__global__ __launch_bounds__(WAVES * 64, ((NG == 1 && WAVES == 4 && RING == 0) ? 4 : 1)) void k_tail(const ClipDesc* __restrict__ clips,
                                                           const ClipInfo* __restrict__ info,
                                                           const float* __restrict__ dctP, KParams kp,
                                                           const float* __restrict__ logmel,
@@ -77,7 +87,9 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
   float* const dct_tab = tl_smem;                          // [(g KS + s) 4 + c][64 lanes]
   float* const edge = dct_tab + NCG * KS * 4 * 64;         // [k < 16 NG][18]: frames 0..8, T-9..T-1 of row k
   double* const part = reinterpret_cast<double*>(edge + NCG * 16 * 18 + (((NCG * 16 * 18) & 1) ? 1 : 0));   // [wave][k][2]
-  double* const red = part + kTailWaves * NCG * 16 * 2;   // block reductions of the RMS row: [wave][4]
+  double* const red = part + WAVES * NCG * 16 * 2;        // block reductions of the RMS row: [wave][4]
+  float* const ring = reinterpret_cast<float*>(red + WAVES * 4);      // RING > 0: [wave][RING][16 rows x 128 floats], 16-byte aligned
+  constexpr int kTailWaves = WAVES;
   // coefficient of row i of group g: consecutive, or (SYM) even coefficients in the first GH groups, odd ones in the rest
   auto coef = [&](int g, int i) -> int { return SYM ? 2 * (16 * (g % GH) + i) + g / GH : 16 * g + i; };
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -119,6 +131,20 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
       x[s] = on ? *reinterpret_cast<const float4*>(row + q * 4 + s * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (SYM) x[4 + s] = on ? *reinterpret_cast<const float4*>(row + (3 - q) * 4 + (S - 1 - s) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
+    // ---- LDS-DMA ring (RING > 0)
+    float* const myring = ring + wave * (RING > 0 ? RING : 1) * 2048;
+    auto dma_tile = [&](int tile, int slot) {              // 8 KB: position p = 64 i + lane of the image <- chunk (p & 31) ^ f of row f = p >> 5
+      const float* tb = logmel + (cd.frame_base + g0 + tile * 16) * (int64_t)M;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int fr = 2 * i + (lane >> 5), j = (lane & 31) ^ fr;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + fr * 128 + j * 4),
+                                         (__attribute__((address_space(3))) void*)(myring + slot * 2048 + i * 256), 16, 0, 0);
+      }
+    };
+    auto ring_seg = [&](int slot, int chunk) -> float4 {   // chunk `chunk` (four filters) of this lane's frame row
+      return *reinterpret_cast<const float4*>(myring + slot * 2048 + (f * 32 + (chunk ^ f)) * 4);
+    };
     double sm[NCG][4], sq[NCG][4];
 #pragma unroll
     for (int g = 0; g < NCG; ++g)
@@ -126,9 +152,20 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
       for (int r = 0; r < 4; ++r) { sm[g][r] = 0.0; sq[g][r] = 0.0; }
     float4 xc[8];
     int tile = wave;
+    if constexpr (RING > 0) {
+#pragma unroll
+      for (int r = 0; r < RING; ++r) if (tile + r * kTailWaves < ntiles) dma_tile(tile + r * kTailWaves, r);
+    } else {
 #pragma unroll
     for (int s = 0; s < 8; ++s) if (s < KS) load_seg(tile, s, xc);
+    }
+    int slot = 0;
     for (; tile < ntiles; tile += kTailWaves) {
+      if constexpr (RING > 0) {
+        // this tile's eight DMAs have landed once at most those of the RING - 1 tiles behind it are outstanding
+        if (tile + (RING - 1) * kTailWaves < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (RING - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       tl_f32x4 acc[NCG][2];
 #pragma unroll
       for (int g = 0; g < NCG; ++g) { acc[g][0] = tl_f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = tl_f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -136,6 +173,7 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           if (s < KS) {
+            if constexpr (RING > 0) { xc[s] = ring_seg(slot, 4 * s + q); xc[4 + s] = ring_seg(slot, 4 * (S - 1 - s) + (3 - q)); }
             // clamp first (power_to_db's top_db), then fold: filter m with its mirror M - 1 - m (component c with 3 - c)
             const float u0 = fmaxf(xc[s].x, theta), u1 = fmaxf(xc[s].y, theta), u2 = fmaxf(xc[s].z, theta), u3 = fmaxf(xc[s].w, theta);
             const float w0 = fmaxf(xc[4 + s].w, theta), w1 = fmaxf(xc[4 + s].z, theta), w2 = fmaxf(xc[4 + s].y, theta), w3 = fmaxf(xc[4 + s].x, theta);
@@ -150,13 +188,14 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
               acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[128], ev ? e2 : o2, acc[g][0], 0, 0, 0);
               acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[192], ev ? e3 : o3, acc[g][1], 0, 0, 0);
             }
-            load_seg(tile + kTailWaves, s, xc);
+            if constexpr (RING == 0) load_seg(tile + kTailWaves, s, xc);
           }
         }
       } else {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         if (s < S) {
+          if constexpr (RING > 0) xc[s] = ring_seg(slot, 4 * s + q);
           const float b0 = fmaxf(xc[s].x, theta), b1 = fmaxf(xc[s].y, theta);
           const float b2 = fmaxf(xc[s].z, theta), b3 = fmaxf(xc[s].w, theta);
 #pragma unroll
@@ -167,9 +206,14 @@ __global__ __launch_bounds__(kTailWaves * 64) void k_tail(const ClipDesc* __rest
             acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[128], b2, acc[g][0], 0, 0, 0);
             acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[192], b3, acc[g][1], 0, 0, 0);
           }
-          load_seg(tile + kTailWaves, s, xc);
+          if constexpr (RING == 0) load_seg(tile + kTailWaves, s, xc);
         }
       }
+      }
+      if constexpr (RING > 0) {
+        // every operand read of this slot has returned (its MFMAs were issued): refill it RING tiles on
+        if (tile + RING * kTailWaves < ntiles) dma_tile(tile + RING * kTailWaves, slot);
+        slot = slot + 1 == RING ? 0 : slot + 1;
       }
       const int t = tile * 16 + f;
       const bool live = t < T;
@@ -303,25 +347,31 @@ int tail_sym_groups(const KParams& kp, const DevTables& tb) {
   return gh < ncg ? gh : 0;
 }
 
-static size_t tail_lds_bytes(int ng, int ks) {
-  const size_t tab = (size_t)ng * ks * 4 * 64, edge = (size_t)ng * 16 * 18 + 1;
-  return (tab + edge) * sizeof(float) + ((size_t)kTailWaves * ng * 16 * 2 + kTailWaves * 4) * sizeof(double) + 16;
+static size_t tail_lds_bytes(int ng, int ks, int waves, int ring) {
+  const size_t tab = (size_t)ng * ks * 4 * 64, edge = (size_t)ng * 16 * 18 + (((ng * 16 * 18) & 1) ? 1 : 0);
+  return (tab + edge) * sizeof(float) + ((size_t)waves * ng * 16 * 2 + waves * 4) * sizeof(double) +
+         (size_t)waves * ring * 2048 * sizeof(float) + 16;
 }
 
-template <int NG, bool SYM>
+template <int NG, bool SYM, int WAVES, int RING>
 static hipError_t launch_tail_t(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const float* table, const KParams& kp,
                                 const float* logmel, const float* rms_rows, float* stats, ClipInfo* info_out, int n_clips,
                                 int spec, int n_cu) {
-  const size_t lds = tail_lds_bytes(NG, SYM ? kp.n_mels / 32 : kp.n_mels / 16);
+  const size_t lds = tail_lds_bytes(NG, SYM ? kp.n_mels / 32 : kp.n_mels / 16, WAVES, RING);
   // as many workgroups as the chip holds at once (asked of the runtime once per instantiation), each walking its share of the clips
   static int per_cu = 0;
   if (per_cu == 0) {
+    const void* fn = reinterpret_cast<const void*>(&k_tail<NG, SYM, WAVES, RING>);
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+    }
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_tail<NG, SYM>), kTailWaves * 64, lds) != hipSuccess || nb < 1) nb = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVES * 64, lds) != hipSuccess || nb < 1) nb = 1;
     per_cu = std::min(nb, 8);
   }
-  dim3 grid(std::max(1, std::min(n_clips, n_cu * per_cu))), block(kTailWaves * 64);
-  hipLaunchKernelGGL((k_tail<NG, SYM>), grid, block, lds, s, clips, info, table, kp, logmel, rms_rows, stats, info_out, spec, n_clips);
+  dim3 grid(std::max(1, std::min(n_clips, n_cu * per_cu))), block(WAVES * 64);
+  hipLaunchKernelGGL((k_tail<NG, SYM, WAVES, RING>), grid, block, lds, s, clips, info, table, kp, logmel, rms_rows, stats, info_out, spec, n_clips);
   return hipGetLastError();
 }
 
@@ -329,7 +379,12 @@ hipError_t launch_tail(hipStream_t s, const ClipDesc* clips, const ClipInfo* inf
                        const float* logmel, const float* rms_rows, float* stats, ClipInfo* info_out, int n_clips, int spec,
                        int n_cu) {
   const int gh = tail_sym_groups(kp, tb);
-#define AFX_TAIL(NG, SYM, TAB) launch_tail_t<NG, SYM>(s, clips, info, TAB, kp, logmel, rms_rows, stats, info_out, n_clips, spec, n_cu)
+  // mode: 0 the shipped choice; 1 registers; 2 LDS-DMA ring, 4 waves x 4 tiles; 3 LDS-DMA ring, 8 waves x 2 tiles (A/B: AFX_TAIL_MODE)
+  int mode = dev_env().tail_mode;
+  if (kp.n_mels != 128) mode = 1;                          // the ring's image is laid out for 512-byte rows
+  else if (mode == 0) mode = 3;
+#define AFX_TAIL_W(NG, SYM, TAB, W, R) launch_tail_t<NG, SYM, W, R>(s, clips, info, TAB, kp, logmel, rms_rows, stats, info_out, n_clips, spec, n_cu)
+#define AFX_TAIL(NG, SYM, TAB) (mode == 2 ? AFX_TAIL_W(NG, SYM, TAB, 4, 4) : mode == 3 ? AFX_TAIL_W(NG, SYM, TAB, 8, 2) : AFX_TAIL_W(NG, SYM, TAB, 4, 0))
   if (gh == 1) return AFX_TAIL(2, true, tb.dctS);
   if (gh == 2) return AFX_TAIL(4, true, tb.dctS);
   switch ((kp.n_mfcc + 15) / 16) {
@@ -339,6 +394,7 @@ hipError_t launch_tail(hipStream_t s, const ClipDesc* clips, const ClipInfo* inf
     default: return hipErrorInvalidValue;
   }
 #undef AFX_TAIL
+#undef AFX_TAIL_W
 }
 
 }  // namespace afx
