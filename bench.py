@@ -8,7 +8,8 @@ Workload (default BASELINE.json configs[1]; configs[3] = the same per GPU when N
 HBM when the timed region starts.  --config 3 / 5 run BASELINE.json configs[2] / configs[4] (16 kHz 512/128/40 and
 44.1 kHz 2048/512/20) the same way; they are parity cases with their own roofline lines, not the headline metric.
 One "step" = one pass of preprocess_audio -> extract_mfcc + extract_energy over that batch (frame kernel before the trim
-decision, trim decision, redo launch, DCT, statistics; 4*n_mfcc+3 floats per clip copied back).
+decision, trim decision, redo launch, then k_tail: clamp + DCT + statistics per clip -- timed in the `dct` slot; 4*n_mfcc+3
+floats per clip land in pinned host memory).
 Scaling is weak: every rank owns its own 1000 clips, no data-path collective; the only torch.distributed traffic is
 the timing barrier and the max-over-ranks reduction.  `python bench.py --gpus N` without a launcher starts the N ranks
 itself (children, before anything touches the GPU).
@@ -29,6 +30,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                   union contains the hand-over).  `exclusive` times every kernel of 20 calls made one at a time on a
                   fresh context (what profiles/r02_*_kernel_stats.csv shows);
                   `fp32` the secondary vector-FLOP roofline (BASELINE.md 4);
+  distinct_batches_frames_per_s -- the timed region repeated over --distinct different ragged batches (every submit uploads
+                  new clip records; the device rebuilds its block list): what a window pipeline over real files sees;
   cpu_baseline -- the numpy/scipy oracle (a port of the reference's librosa path) timed on this box's host cores over a
                   bounded sample of the same workload: one core, and a pool over every core this process may use.
 """
