@@ -29,7 +29,12 @@ for sr, n_fft, hop, K in ((22050, 1024, 256, 13), (16000, 512, 128, 40), (44100,
     outf = plan.extract_batch(buf, offsets, lengths, want_frames=True)
     assert np.array_equal(out["status"], outf["status"]) and np.array_equal(out["trim"], outf["trim"])
     ok = out["status"] == 0
-    assert np.array_equal(out["stats"][ok], outf["stats"][ok]), "statistics differ between the two output modes"
+    # the statistics-only call runs k_tail, the per-frame call k_dct16* + k_stats: equal to a few float32 ulps of the values they
+    # are formed from (row sums in another order, the folded DCT), each value on its own scale floored at 1e-2 of the clip's
+    # largest coefficient mean -- tests/test_gpu_pipeline.py::test_fused_tail_equals_the_two_kernel_tail
+    a, b = out["stats"][ok].astype(np.float64), outf["stats"][ok].astype(np.float64)
+    scale = np.maximum(np.abs(b), 1e-2 * np.abs(b[:, :K]).max(axis=1, keepdims=True))
+    assert (np.abs(a - b) <= 2e-5 * scale).all(), "statistics differ between the two output modes: %g" % (np.abs(a - b) / scale).max()
     checked = short = 0
     for i in rng.choice(len(clips), 70, replace=False):
         try:
