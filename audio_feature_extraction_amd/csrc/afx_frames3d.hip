@@ -176,10 +176,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
         const int g = bd.t0 + 4 * it;
         bool bad;
         if (g == 0) { const float t = rowsum4(rows[8], rows[9], rows[10], rows[11], false, bad); put_sum(t, bad, false, bd, 0); }
+        // the four new sub-blocks at once: per-lane partials q[k], then a butterfly over the 32 lanes of the upper half that
+        // halves the number of live values at every step (lane & 1 picks q0 | q1 and q2 | q3, lane & 2 picks between those),
+        // so that lane 32 + k ends with the total of sub-block g + 1 + k -- 14 vector instructions and one store where four
+        // separate wave reductions (4 DPP steps, two readlanes, a scalar store each) were 60
+        float q[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float t = rowsum4(rows[4 + 4 * k], rows[5 + 4 * k], rows[6 + 4 * k], rows[7 + 4 * k], true, bad);
-          put_sum(t, bad, true, bd, g + 1 + k);
+          q[k] = rows[4 + 4 * k] * rows[4 + 4 * k];
+          q[k] = fmaf(rows[5 + 4 * k], rows[5 + 4 * k], q[k]); q[k] = fmaf(rows[6 + 4 * k], rows[6 + 4 * k], q[k]);
+          q[k] = fmaf(rows[7 + 4 * k], rows[7 + 4 * k], q[k]);
+        }
+        const unsigned long long odd = 0xAAAAAAAAAAAAAAAAull, hi2 = 0xCCCCCCCCCCCCCCCCull;
+        float s01 = f3_sel(q[0], q[1], odd) + F3_DPP(f3_sel(q[1], q[0], odd), 0xB1);       // lane ^ 1
+        float s23 = f3_sel(q[2], q[3], odd) + F3_DPP(f3_sel(q[3], q[2], odd), 0xB1);
+        float sq = f3_sel(s01, s23, hi2) + F3_DPP(f3_sel(s23, s01, hi2), 0x4E);            // lane ^ 2
+        sq += F3_DPP(sq, 0x124); sq += F3_DPP(sq, 0x128);                                   // row_ror 4, 8: the four quads of a row
+        sq = f3_add_xor16(sq);                                                              // the half's two rows
+        const int jk = g + 1 + (lane & 3);
+        if (lane >= 32 && lane < 36 && jk < bd.pad_[1]) bsum[bd.pad_[0] + jk] = sq;
+        if (__any(lane >= 32 && !(fabsf(sq) < INFINITY))) {       // rare: a sum that is not finite -- is it the samples?
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool badk = !(isfinite(rows[4 + 4 * k]) && isfinite(rows[5 + 4 * k]) && isfinite(rows[6 + 4 * k]) && isfinite(rows[7 + 4 * k]));
+            if (g + 1 + k < bd.pad_[1] && __any(badk && lane >= 32) && lane == 0) atomicOr(&info[bd.clip].nonfinite, 1u);
+          }
         }
       }
       // ---- z = w yA + i w yB
