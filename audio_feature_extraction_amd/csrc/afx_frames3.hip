@@ -26,7 +26,7 @@
 //
 // FFT schedule (unchanged mathematics from k_frames2): z = w*yA + i*w*yB, 1024 points as 16 x 8 x 8,
 //   pass 1  radix 16 over u (lane l holds points l + 64 u)                 -> Y[l][k1]
-//   xchg 1  image [l][17] (one pad slot per row: base + immediate on both sides), lane reads l_src = (l>>4) + 4u, k1 = l & 15
+//   xchg 1  image [k1][66] (transposed; base + immediate on both sides, conflict-free both ways), lane reads l_src = (l>>4) + 4u, k1 = l & 15
 //   pass 2  two radix-8 butterflies (a = (l>>4) + 4i, over r: l_src = a + 8r), twiddle W_128^(k1 r)
 //   xchg 2  image [a][128] at j = k1 + 16 k2, plain layout (both sides conflict-free)
 //   pass 3  radix 8 over a for butterflies ja = l and jb = 128 - l (lane 0: 0 and 64), twiddle W_1024^(a j):
@@ -135,8 +135,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
   const int M = kp.n_mels;
   const int jb = lane ? 128 - lane : 64;
   // image slots (float2 units)
-  v2* const e1w = E + 17 * lane;
-  const v2* const e1r = E + 17 * (lane >> 4) + (lane & 15);
+  // exchange-1 image [k1][66] (transposed, row stride 66 = 2 mod 32): a lane stores its value k at row k, column = its own
+  // index -- 16 consecutive lanes, consecutive slots: conflict-free -- and reads row k1 = lane & 15 at column (lane >> 4) + 4 u:
+  // the two 16-lane quarters of a 32-lane read group differ by one column, i.e. fall on the even / the odd slots of
+  // 2 k1 + column -- conflict-free as well (round 2's [l][17] image had one 2-way conflict per read: 16 LDS cycles a pass)
+  v2* const e1w = E + lane;
+  const v2* const e1r = E + 66 * (lane & 15) + (lane >> 4);
   v2* const e2w = E + 128 * (lane >> 4) + (lane & 15);
   v2* const ea = E + lane;                 // pass-3 reads of butterfly ja; power-spectrum bins lane + 128 s
   v2* const eb = E + jb;                   // butterfly jb; bins jb + 384 - 128 (s - 4)
@@ -284,9 +288,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3(const void* __restrict__
       f3_dft16(z, H, W1, W3);
       if (!F3_SKIP(0x200)) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) stv(e1w + k, z[k]);       // stv: two ds_write_b64 (2 x 6 cycles), not a merged ds_write2_b64 (13)
+      for (int k = 0; k < 16; ++k) stv(e1w + 66 * k, z[k]);       // stv: two ds_write_b64 (2 x 6 cycles), not a merged ds_write2_b64 (13)
 #pragma unroll
-      for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 68 * u);
+      for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 4 * u);
       }
       // ---- pass 2 + exchange 2
       {

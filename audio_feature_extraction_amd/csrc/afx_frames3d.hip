@@ -88,8 +88,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
   const float b1 = kp.preemph_b1;
   const int M = kp.n_mels;
   const int jb0 = lp ? 128 - lp : 64, ja1 = lp + 32, jb1 = 96 - lp;
-  v2* const e1w = E + 17 * lp;
-  const v2* const e1r = E + 17 * (lp >> 4) + (lp & 15);
+  // exchange-1 image [k1][34] (transposed, row stride 34 = 2 mod 32): a lane stores its value k at row k, column = its own
+  // index -- 16 consecutive lanes, consecutive slots: conflict-free -- and reads row k1 = lp & 15 at column (lp >> 4) + 2 u:
+  // the two 16-lane quarters of a 32-lane read group differ by one column, i.e. fall on the even / the odd slots of
+  // 2 k1 + column -- conflict-free as well (round 2's [l][17] image had one 2-way conflict per read: 16 LDS cycles a pass)
+  v2* const e1w = E + lp;
+  const v2* const e1r = E + 34 * (lp & 15) + (lp >> 4);
   v2* const e2w = E + 128 * (lp >> 4) + (lp & 15);
 
   auto raw_ld = [&](int64_t idx) -> float {
@@ -214,9 +218,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3d(const void* __restrict_
       // ---- pass 1 + exchange 1 (this half's image)
       f3_dft16(z, H, W1, W3);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) stv(e1w + k, z[k]);       // unmerged 8-byte stores: 2 x 6 LDS cycles against 13 for ds_write2_b64
+      for (int k = 0; k < 16; ++k) stv(e1w + 34 * k, z[k]);       // unmerged 8-byte stores: 2 x 6 LDS cycles against 13 for ds_write2_b64
 #pragma unroll
-      for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 34 * u);
+      for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 2 * u);
       // ---- pass 2 + exchange 2
       {
         v2 tw[8];

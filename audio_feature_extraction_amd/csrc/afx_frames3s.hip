@@ -102,8 +102,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
   const int M = kp.n_mels;
   const int jb = lane ? 128 - lane : 64;
   const int lq = lane ? lane : 64;         // first bin of the lane's pairs 4..7 (minus 128 s)
-  v2* const e1w = E + 17 * lane;
-  const v2* const e1r = E + 17 * (lane >> 4) + (lane & 15);
+  // exchange-1 image [k1][66] (transposed, row stride 66 = 2 mod 32): a lane stores its value k at row k, column = its own
+  // index -- 16 consecutive lanes, consecutive slots: conflict-free -- and reads row k1 = lane & 15 at column (lane >> 4) + 4 u:
+  // the two 16-lane quarters of a 32-lane read group differ by one column, i.e. fall on the even / the odd slots of
+  // 2 k1 + column -- conflict-free as well (round 2's [l][17] image had one 2-way conflict per read: 16 LDS cycles a pass)
+  v2* const e1w = E + lane;
+  const v2* const e1r = E + 66 * (lane & 15) + (lane >> 4);
   v2* const e2w = E + 128 * (lane >> 4) + (lane & 15);
   const v2* const ea = E + lane;
   const v2* const eb = E + jb;
@@ -221,9 +225,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_frames3s(const void* __restrict_
       // ---- 1024-point complex FFT (k_frames3's schedule)
       f3_dft16(z, H, W1, W3);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) stv(e1w + k, z[k]);       // unmerged 8-byte stores: 2 x 6 LDS cycles against 13 for ds_write2_b64
+      for (int k = 0; k < 16; ++k) stv(e1w + 66 * k, z[k]);       // unmerged 8-byte stores: 2 x 6 LDS cycles against 13 for ds_write2_b64
 #pragma unroll
-      for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 68 * u);
+      for (int u = 0; u < 16; ++u) z[u] = ldv(e1r + 4 * u);
       {
         v2 tw[8];
 #pragma unroll

@@ -200,3 +200,47 @@ def test_fused_tail_equals_the_two_kernel_tail(sr, n_fft, hop, n_mfcc):
         else:
             assert np.array_equal(a, b), i                           # zeros, or the energy statistics alone
     assert one["stats"][5][4 * K] > 0.0 and not one["stats"][5][:4 * K].any()
+
+
+_SWITCH_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from audio_feature_extraction_amd import _native as N
+from audio_feature_extraction_amd.synth import make_clip
+from tests.parity import check_stats, oracle_stats
+for sr, n_fft, hop, K in ((22050, 1024, 256, 13), (16000, 512, 128, 40), (44100, 2048, 512, 20)):
+    clips = [make_clip(700 + i, sr, 0.5 + 0.1 * (i % 6), speechy=(i % 3 == 0)) for i in range(40)]
+    lens = np.array([c.size for c in clips], np.int64)
+    offs = np.zeros(len(clips), np.int64); offs[1:] = np.cumsum((lens + 3) // 4 * 4)[:-1]
+    buf = np.zeros(int(offs[-1] + lens[-1]) + 8, np.float32)
+    for c, o in zip(clips, offs): buf[o:o + c.size] = c
+    ctx = N.Context(0); plan = N.Plan(ctx, N.make_params(sr, n_fft, hop, K))
+    pin = plan.pinned_buffer(buf.nbytes); host = pin.array(np.float32, buf.size); host[:] = buf      # page-locked source
+    a = plan.extract_batch(host, offs, lens)
+    b = plan.extract_batch(host, offs + 0, lens - 1)          # new lengths: the block list is rebuilt
+    a2 = plan.extract_batch(host, offs, lens)
+    assert np.array_equal(a["stats"], a2["stats"]) and (a["status"] == 0).all() and (b["status"] == 0).all()
+    for i in range(0, len(clips), 7):
+        check_stats(a["stats"][i], oracle_stats(clips[i], sr, n_fft, hop, K), K, "clip %d" % i)
+        check_stats(b["stats"][i], oracle_stats(clips[i][:-1], sr, n_fft, hop, K), K, "cut clip %d" % i)
+    pin.free(); plan.close(); ctx.close()
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"AFX_TAIL_MODE": "1"}, {"AFX_TAIL_MODE": "2"}, {"AFX_TAIL_MODE": "3"}, {"AFX_NO_FUSED_TAIL": "1"},
+                                 {"AFX_HOST_BLOCKS": "1"}, {"AFX_F3_GENERIC_MEL": "1"}, {"AFX_NO_SPEC": "1"}, {"AFX_F3_WAVES": "12"}])
+def test_every_ab_switch_is_parity_green(env):
+    """The developer switches (afx_devenv.h) select other kernels / other routes for the same results: the register-path and
+    both LDS-DMA forms of k_tail, the two-kernel tail, the host-built block list, the generic mel walk, the two-pass
+    pipeline, 12-wave workgroups.  They are read once per process, so each runs in a child process; every one has to match
+    the oracle on the three BASELINE shapes, from a page-locked host buffer (afx_host_alloc), with a batch of new lengths
+    in between (k_build_blocks3)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _SWITCH_SCRIPT.format(root=root)], env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-1500:], r.stderr[-3000:])
