@@ -15,7 +15,8 @@
  *   - the caller owns every buffer it passes; the library never frees them;
  *   - an afx_ctx is bound to one HIP device and owns one stream; it is not
  *     thread-safe -- use one ctx per worker thread (one per GPU);
- *   - all entry points are synchronous on return;
+ *   - all entry points are synchronous on return, except afx_extract_submit (its results are
+ *     handed out by afx_extract_collect);
  *   - a per-clip failure is reported in out_status[] and never fails the batch
  *     (maps onto batch_process's per-file try/except, F:229-235).
  */
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AFX_VERSION 103
+#define AFX_VERSION 104      /* 104: afx_batch_geometry, afx_host_alloc / afx_host_free */
 
 typedef enum afx_status {
   AFX_OK = 0,
