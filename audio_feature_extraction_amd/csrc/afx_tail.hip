@@ -358,9 +358,14 @@ static hipError_t launch_tail_t(hipStream_t s, const ClipDesc* clips, const Clip
                                 const float* logmel, const float* rms_rows, float* stats, ClipInfo* info_out, int n_clips,
                                 int spec, int n_cu) {
   const size_t lds = tail_lds_bytes(NG, SYM ? kp.n_mels / 32 : kp.n_mels / 16, WAVES, RING);
-  // as many workgroups as the chip holds at once (asked of the runtime once per instantiation), each walking its share of the clips
-  static int per_cu = 0;
-  if (per_cu == 0) {
+  // as many workgroups as the chip holds at once (asked of the runtime once per instantiation and device -- the dynamic-LDS
+  // attribute is per device too: batch_process drives every visible GPU from one process), each walking its share of the clips
+  static int per_cu_dev[64] = {};
+  int dev = 0;
+  hipError_t e0 = hipGetDevice(&dev);
+  if (e0 != hipSuccess) return e0;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (per_cu_dev[dev] == 0) {
     const void* fn = reinterpret_cast<const void*>(&k_tail<NG, SYM, WAVES, RING>);
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -368,8 +373,9 @@ static hipError_t launch_tail_t(hipStream_t s, const ClipDesc* clips, const Clip
     }
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVES * 64, lds) != hipSuccess || nb < 1) nb = 1;
-    per_cu = std::min(nb, 8);
+    per_cu_dev[dev] = std::min(nb, 8);
   }
+  const int per_cu = per_cu_dev[dev];
   dim3 grid(std::max(1, std::min(n_clips, n_cu * per_cu))), block(WAVES * 64);
   hipLaunchKernelGGL((k_tail<NG, SYM, WAVES, RING>), grid, block, lds, s, clips, info, table, kp, logmel, rms_rows, stats, info_out, spec, n_clips);
   return hipGetLastError();
