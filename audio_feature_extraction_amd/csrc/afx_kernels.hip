@@ -1086,6 +1086,9 @@ __global__ __launch_bounds__(256, (NFFT >= 2048 ? 1 : 2)) void k_frames(const vo
   flush_logmel();
 }
 
+// Round 1's 4-wave kernel for 1024 / 256.  Since round 2 the wave-level k_frames3 serves that shape; this one is reachable only
+// through AFX_NO_FRAMES3 and is compiled only into the diagnostic library (make dbg: -DAFX_WITH_FRAMES2), not into libafx.so.
+#ifdef AFX_WITH_FRAMES2
 // ---------------------------------------------------------------------------
 // k_frames2: the n_fft = 1024 kernel.  Differences from the generic k_frames above:
 //   * two real frames ride one 1024-point complex FFT (z = xA + i*xB): X_A[k], X_B[k] follow from
@@ -1549,6 +1552,7 @@ __global__ __launch_bounds__(256, 2) void k_frames2(const void* __restrict__ sam
   if constexpr (STAMP) { if (lane == 0) for (int i = 0; i < ST_COUNT; ++i) stamps[((size_t)blockIdx.x * kWaves + wave) * ST_COUNT + i] = st_sum[i]; }
   flush_logmel();
 }
+#endif  // AFX_WITH_FRAMES2
 
 // ---------------------------------------------------------------------------
 // k_dct: clamp at (clip max - top_db), ortho DCT-II on the matrix pipe.
@@ -1851,9 +1855,14 @@ hipError_t launch_trim_decide(hipStream_t s, const ClipDesc* clips, ClipInfo* in
 }
 
 bool frames2_eligible(const KParams& kp, const DevTables& tb) {
+#ifndef AFX_WITH_FRAMES2
+  (void)kp; (void)tb;
+  return false;
+#else
   const int per = kp.hop > 0 ? kp.trim_hop / kp.hop : 0;
   return kp.n_fft == 1024 && kp.hop == 256 && tb.mel_ntaps > 0 && frames2_lds_bytes(tb.mel_ntaps) <= 80 * 1024 && kp.n_mels <= 128 &&
          kp.trim_hop % kp.hop == 0 && per >= 1 && per <= 4 && !dev_env().generic_1024;
+#endif
 }
 
 template <int NFFT>
@@ -1883,6 +1892,7 @@ static hipError_t launch_frames_t(hipStream_t s, const void* samples, ClipInfo* 
   return hipGetLastError();
 }
 
+#ifdef AFX_WITH_FRAMES2
 template <int FMT, bool STAMP, bool DBG>
 static hipError_t launch_frames2_t(hipStream_t s, const void* samples, ClipInfo* info, const BlockDesc* blocks,
                                    int nblocks, const DevTables& tb, const KParams& kp, float* logmel,
@@ -1902,9 +1912,12 @@ static hipError_t launch_frames2_t(hipStream_t s, const void* samples, ClipInfo*
   return hipGetLastError();
 }
 
+#endif  // AFX_WITH_FRAMES2
+
 hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
                          const BlockDesc* blocks, int nblocks, const DevTables& tb, const KParams& kp,
                          float* logmel, float* rms_rows, int grid, unsigned long long* stamps) {
+#ifdef AFX_WITH_FRAMES2
   if (frames2_eligible(kp, tb) && kp.rms_sub > 0) {
     const bool dbg = (kp.flags & 0x7f00) != 0 || stamps != nullptr;     // ablation switches / stamps: diagnostic instantiations
 #define AFX_F2(FMT)                                                                                              \
@@ -1915,6 +1928,7 @@ hipError_t launch_frames(hipStream_t s, const void* samples, ClipInfo* info,
     return AFX_F2(AFX_FMT_F32);
 #undef AFX_F2
   }
+#endif
   switch (kp.n_fft) {
     case 256:  return launch_frames_t<256>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
     case 512:  return launch_frames_t<512>(s, samples, info, blocks, nblocks, tb, kp, logmel, rms_rows, grid, stamps);
