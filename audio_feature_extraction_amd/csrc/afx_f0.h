@@ -12,7 +12,7 @@
 namespace afx {
 
 constexpr int kF0Thresholds = 100;     // librosa.pyin n_thresholds
-constexpr int kF0FramesPerBlock = 16;  // frames one workgroup of k_f0_yin owns
+constexpr int kF0FramesPerBlock = 16;  // frames one workgroup of k_f0_yin owns at most (8 where that fits a third workgroup per CU)
 
 struct F0Params {
   int32_t n_fft, hop, W;               // frame_length, hop_length, win_length = frame_length / 2

@@ -205,21 +205,36 @@ __global__ __launch_bounds__(64 * kEnergyWaves) void k_f0_energy(const float* __
 // ---------------------------------------------------------------------------------------------
 
 struct YinLds { size_t span, per_wave, tables, total; };
-__host__ __device__ inline YinLds yin_lds(const F0Params& fp) {
+__host__ __device__ inline YinLds yin_lds(const F0Params& fp, int fpb, bool yf) {
   YinLds L;
-  L.span = (size_t)(kF0FramesPerBlock - 1) * fp.hop + fp.n_fft + 64;
+  L.span = (size_t)(fpb - 1) * fp.hop + fp.n_fft + 64;
   // per wave (doubles): D[n_tau_pad] | X[slots*64 + 2] | CP[cap] | CB[cap] (ints, cap/2 doubles)
   L.per_wave = (size_t)fp.n_tau_pad + (size_t)fp.slots * 64 + 2 + fp.cap + (fp.cap + 1) / 2;
   // shared tables: thr[101] | beta[100] | cumbeta[101] | bfact[cap+1] | bexp[cap+1]
   L.tables = 101 + 100 + 101 + 2 * ((size_t)fp.cap + 1);
-  L.total = (L.span + 4 * L.per_wave + L.tables) * sizeof(double);
+  // the staged signal is kept as the float32 it is (converted on read: half the bytes of the autocorrelation's LDS reads and
+  // 20 KB less per workgroup); span is rounded up to an even count so that the double arrays behind it stay 8-byte aligned
+  // (yf: the instantiations with at most 6 lags per lane; the lag-heavy ones re-read the signal 11..16 times per step and keep it
+  // as float64 -- a conversion per read costs them more than the bytes)
+  L.span = (L.span + 1) & ~(size_t)1;
+  L.total = L.span * (yf ? sizeof(float) : sizeof(double)) + (4 * L.per_wave + L.tables) * sizeof(double);
   return L;
 }
-size_t f0_yin_lds_bytes(const F0Params& fp) { return yin_lds(fp).total; }
+// frames one workgroup owns: 16, or 8 where that (and only that) lets a third workgroup onto the CU -- the kernel is bound by
+// how often a wave gets to issue, and the lag-heavy instantiations (more than 6 lags per lane) cannot use a third wave anyway
+int f0_yin_frames_per_block(const F0Params& fp) {
+  const int need = fp.R > fp.slots ? fp.R : fp.slots;
+  const size_t third = 160 * 1024 / 3;
+  return (need <= 6 && yin_lds(fp, 16, true).total > third && yin_lds(fp, 8, true).total <= third) ? 8 : 16;
+}
+size_t f0_yin_lds_bytes(const F0Params& fp) {
+  const int need = fp.R > fp.slots ? fp.R : fp.slots;
+  return yin_lds(fp, f0_yin_frames_per_block(fp), need <= 6).total;
+}
 
 // RR >= lags per lane (fp.R), SS >= trough slots per lane (fp.slots): per-lane arrays are sized by them
-template <int RR, int SS>
-__global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
+template <int RR, int SS, int FPB>
+__global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* __restrict__ ysig,
                                                 const ClipDesc* __restrict__ clips,
                                                 const ClipInfo* __restrict__ info,
                                                 const float* __restrict__ energy,
@@ -233,20 +248,23 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
   const ClipInfo ci = info[clip];
   if (ci.status == AFX_CLIP_NONFINITE) return;
   const int T = ci.T;
-  const int t0 = blockIdx.x * kF0FramesPerBlock;
+  const int t0 = blockIdx.x * FPB;
   if (t0 >= T) return;
   const ClipDesc cd = clips[clip];
   const int64_t np = ci.end - ci.start;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const YinLds L = yin_lds(fp);
-  double* Y = smy;
-  double* D = smy + L.span + (size_t)wave * L.per_wave;
+  constexpr bool YF = RR <= 6;
+  typedef typename std::conditional<YF, float, double>::type ysig_t;
+  const YinLds L = yin_lds(fp, FPB, YF);
+  ysig_t* Y = reinterpret_cast<ysig_t*>(smy);
+  double* const smd = smy + (YF ? L.span / 2 : L.span);       // the double arrays behind the staged signal
+  double* D = smd + (size_t)wave * L.per_wave;
   double* X = D + fp.n_tau_pad;
   double* CP = X + fp.slots * 64 + 2;
   int* CB = reinterpret_cast<int*>(CP + fp.cap);
   const int hop = fp.hop, W = fp.W, R = fp.R, slots = fp.slots, n_lag = fp.n_lag;
   // the probability tables are read inside the threshold loop with data-dependent indices: keep them in LDS
-  double* Tthr = smy + L.span + 4 * L.per_wave;
+  double* Tthr = smd + 4 * L.per_wave;
   double* Tbeta = Tthr + 101;
   double* Tcum = Tbeta + 100;
   double* Tfact = Tcum + 101;
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
     const float* y = ysig + cd.off;
     for (int i = tid; i < (int)L.span; i += 256) {
       const int64_t g = g0 + i;
-      Y[i] = (g >= 0 && g < np) ? (double)y[g] : 0.0;
+      Y[i] = (g >= 0 && g < np) ? (ysig_t)y[g] : (ysig_t)0;
     }
   }
   __syncthreads();
@@ -282,12 +300,12 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
   double carry[RR];
 #pragma unroll
   for (int r = 0; r < RR; ++r) carry[r] = 0.0;
-  for (int fi = 0; fi < kF0FramesPerBlock / 4; ++fi) {
-    const int f = wave * (kF0FramesPerBlock / 4) + fi;
+  for (int fi = 0; fi < FPB / 4; ++fi) {
+    const int f = wave * (FPB / 4) + fi;
     const int t = t0 + f;
     if (t >= T) break;                                   // wave-uniform
     const int64_t slot = cd.frame_base + t;
-    const double* F = Y + (size_t)f * hop;
+    const ysig_t* F = Y + (size_t)f * hop;
 
     stamp(-1);
     // ---- autocorrelation acf[tau] = sum_{i=1..W} y[i] y[i + tau]  (what irfft(rfft(y) rfft(y[W:0:-1])) [W:] is).
@@ -297,16 +315,16 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
     // The window is walked 64 steps apart together: for i = i0 + 64 g the operand y[i + lane + 64 r] is the one of
     // (i0, r + g), so G steps share G + RR - 1 window reads instead of G * RR -- the loop is bound by LDS bandwidth
     // (eight waves per CU reading 512 bytes per operand), and this cuts its traffic by ~2.5.
-    auto chunk_g = [&](const double* base, double (&out)[RR], auto Gt) {
+    auto chunk_g = [&](const ysig_t* base, double (&out)[RR], auto Gt) {
       constexpr int G = decltype(Gt)::value;
 #pragma unroll 2
       for (int i0 = 1; i0 <= 64; ++i0) {
-        const double* q = base + i0 + lane;
+        const ysig_t* q = base + i0 + lane;
         double v[G + RR - 1], yg[G];
 #pragma unroll
-        for (int m = 0; m < G + RR - 1; ++m) v[m] = q[64 * m];
+        for (int m = 0; m < G + RR - 1; ++m) v[m] = (double)q[64 * m];
 #pragma unroll
-        for (int g = 0; g < G; ++g) yg[g] = base[i0 + 64 * g];
+        for (int g = 0; g < G; ++g) yg[g] = (double)base[i0 + 64 * g];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
         }
       }
     };
-    auto chunk = [&](const double* base, int len, double (&out)[RR]) {     // out[r] = sum_{i=1..len} base[i] base[i + lane + 64 r]
+    auto chunk = [&](const ysig_t* base, int len, double (&out)[RR]) {     // out[r] = sum_{i=1..len} base[i] base[i + lane + 64 r]
 #pragma unroll
       for (int r = 0; r < RR; ++r) out[r] = 0.0;
       if (len == 256) { chunk_g(base, out, std::integral_constant<int, 4>()); return; }
@@ -322,10 +340,10 @@ __global__ __launch_bounds__(256) void k_f0_yin(const float* __restrict__ ysig,
       if (len == 128) { chunk_g(base, out, std::integral_constant<int, 2>()); return; }
 #pragma unroll 4
       for (int i = 1; i <= len; ++i) {
-        const double yi = base[i];
-        const double* q = base + i + lane;
+        const double yi = (double)base[i];
+        const ysig_t* q = base + i + lane;
 #pragma unroll
-        for (int r = 0; r < RR; ++r) out[r] = fma(yi, q[64 * r], out[r]);
+        for (int r = 0; r < RR; ++r) out[r] = fma(yi, (double)q[64 * r], out[r]);
       }
     };
     if (shared_chunks) {
@@ -1006,21 +1024,24 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
                          int32_t* cand_cnt, double* cand_vp, int16_t* cand_bin, double* cand_prob,
                          int n_clips, int max_tmax) {
   const size_t lds = f0_yin_lds_bytes(fp);
-  dim3 grid((max_tmax + kF0FramesPerBlock - 1) / kF0FramesPerBlock, n_clips);
+  const int fpb = f0_yin_frames_per_block(fp);
+  dim3 grid((max_tmax + fpb - 1) / fpb, n_clips);
   const int need = fp.R > fp.slots ? fp.R : fp.slots;
-#define AFX_YIN_LAUNCH(N)                                                                                       \
+#define AFX_YIN_LAUNCH_F(N, F)                                                                                  \
   do {                                                                                                         \
-    hipError_t e2 = allow_lds(k_f0_yin<N, N>, lds);                                                            \
+    hipError_t e2 = allow_lds(k_f0_yin<N, N, F>, lds);                                                         \
     if (e2 != hipSuccess) return e2;                                                                           \
-    hipLaunchKernelGGL((k_f0_yin<N, N>), grid, dim3(256), lds, s, ysig, clips, info, energy, tb, fp, cand_cnt, \
+    hipLaunchKernelGGL((k_f0_yin<N, N, F>), grid, dim3(256), lds, s, ysig, clips, info, energy, tb, fp, cand_cnt, \
                        cand_vp, cand_bin, cand_prob);                                                          \
   } while (0)
+#define AFX_YIN_LAUNCH(N) do { if (fpb == 8) AFX_YIN_LAUNCH_F(N, 8); else AFX_YIN_LAUNCH_F(N, 16); } while (0)
   if (need <= 4) AFX_YIN_LAUNCH(4);
   else if (need <= 6) AFX_YIN_LAUNCH(6);
-  else if (need <= 8) AFX_YIN_LAUNCH(8);
-  else if (need <= 11) AFX_YIN_LAUNCH(11);
-  else AFX_YIN_LAUNCH(16);
+  else if (need <= 8) AFX_YIN_LAUNCH_F(8, 16);
+  else if (need <= 11) AFX_YIN_LAUNCH_F(11, 16);
+  else AFX_YIN_LAUNCH_F(16, 16);
 #undef AFX_YIN_LAUNCH
+#undef AFX_YIN_LAUNCH_F
   return hipGetLastError();
 }
 

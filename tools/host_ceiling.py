@@ -40,9 +40,27 @@ class FakeBuf:
         pass
 
 
+class FakePinned:
+    """Stands in for _native.PinnedBuffer: a block that is allocated and touched once and then reused by the worker's pool, as
+    page-locked memory is -- a fresh np.empty per window would charge the reader threads a page fault per 4 KB."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self._a = np.zeros(self.nbytes, np.uint8)
+
+    def array(self, dtype, count):
+        return self._a[: count * np.dtype(dtype).itemsize].view(dtype)
+
+    def free(self):
+        self._a = None
+
+
 class FakePlan:
     def device_buffer(self, nbytes):
         return FakeBuf()
+
+    def pinned_buffer(self, nbytes):
+        return FakePinned(nbytes)
 
     def extract_submit(self, dbuf, offs, lens, flags=0, fmt=0):
         self.n = len(offs)
