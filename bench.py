@@ -397,10 +397,16 @@ def main() -> None:
         xb.free(); xp.close(); xc.close()
     # the untimed warm-up steps sit directly in front of the timed region: the two measurements above ran on other plans /
     # from host memory, and the lanes' first steps after them pay for it (their workspace is out of the TLB and the caches)
-    run_steps(max(args.warmup, 8))
+    # (with the frame-kernel events already switched on: their first records are not free either)
     if not args.no_timing_events:
         for ln in lanes:
             ln["plan"].set_timing(True, frames_only=True)      # one event pair per step: the kernel the roofline is about
+    # at least 32 of them whatever --warmup says (about 20 ms): after the idle gaps of the set-up the clocks take about that
+    # long to come back -- a 20-step region behind 8 warm-up steps ran 4-5 % below the same region behind 20 (same-box,
+    # profiles/r03_ab_runs.txt); a job that streams batches is in the warmed state
+    run_steps(max(args.warmup, 32))
+    if not args.no_timing_events:
+        for ln in lanes:
             ln["plan"].timings(reset=True)
     fence()
     t0 = time.perf_counter()
