@@ -809,7 +809,7 @@ static int f0_setup(afx_plan* pl, double fmin, double fmax) {
     return AFX_ERR_UNSUPPORTED;
   }
   if (f0_energy_lds_bytes(ht.p) > 160 * 1024 || f0_yin_lds_bytes(ht.p) > 160 * 1024 ||
-      f0_viterbi_lds_bytes(ht.p) > 160 * 1024) {
+      f0_viterbi_lds_bytes(ht.p) > 160 * 1024 || f0_backtrack_lds_bytes(ht.p) > 160 * 1024 || 2 * ht.p.band + 1 > 64) {
     set_error("afx_f0_batch: frame_length / f0 range needs more than 160 KiB of LDS");
     return AFX_ERR_UNSUPPORTED;
   }

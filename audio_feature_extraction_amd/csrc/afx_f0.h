@@ -59,6 +59,7 @@ bool build_f0_tables(int sr, int n_fft, int hop, double fmin, double fmax, HostF
 size_t f0_energy_lds_bytes(const F0Params& fp);
 size_t f0_yin_lds_bytes(const F0Params& fp);
 size_t f0_viterbi_lds_bytes(const F0Params& fp);
+size_t f0_backtrack_lds_bytes(const F0Params& fp);   // also requires 2 band + 1 <= 64 (a lane per source of the band)
 
 // per-frame candidate record sizes (device workspace)
 inline size_t f0_cand_bins_bytes(const F0Params& fp, int64_t frames) { return (size_t)frames * fp.cap * sizeof(int16_t); }

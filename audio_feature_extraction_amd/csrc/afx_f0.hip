@@ -604,6 +604,11 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
 // (numpy's argmax rule) -- bit-identical to forming all pointers up front.
 // ---------------------------------------------------------------------------------------------
 constexpr int kVitThreads = 640;
+__device__ __forceinline__ int vit_role(int hw) {       // hardware wave -> the block of 64 targets it owns (a permutation)
+  if (kVitThreads != 640) return hw;
+  const unsigned long long roles = 0x1876549032ull;    // hw 0..9 -> 2 3 0 9 4 5 6 7 8 1 (nibble per wave, low first)
+  return (int)((roles >> (4 * hw)) & 15);
+}
 
 struct VitLds { size_t v, olp, lt, red, total; };
 __host__ __device__ inline VitLds vit_lds(const F0Params& fp) {
@@ -642,15 +647,10 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
                                                                const double* __restrict__ cand_lp,
                                                                const double* __restrict__ cand_lu,
                                                                double* __restrict__ vrows,
-                                                               VitBest* __restrict__ vbest,
-                                                               uint16_t* __restrict__ states,
-                                                               double* __restrict__ out_stats,
-                                                               double* __restrict__ out_f0,
-                                                               const int64_t* __restrict__ f0_offsets) {
+                                                               VitBest* __restrict__ vbest) {
   extern __shared__ double smv[];
   const int clip = blockIdx.x;
   const ClipInfo ci = info[clip];
-  double* st = out_stats + (size_t)clip * 4;
   // AFX_F0_DEBUG & 16: per-phase cycle counts of workgroup 0, printed per wave (developer aid)
   unsigned long long ph[8] = {}, ph_t = 0;
   auto stamp = [&](int i) {
@@ -663,15 +663,16 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
       ph_t = now;
     }
   };
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = kVitThreads / 64;
   static_assert(NW <= 16, "the per-wave partials are combined inside one DPP row");
+  // A workgroup's ten waves land 3 / 3 / 2 / 2 on the CU's four SIMDs (wave w on SIMD w % 4), and so do those of the
+  // second workgroup of the CU.  The two waves that own the targets next to the range ends issue about 1.6 times the
+  // instructions of the others (the edge-class sources, below): they take the two SIMDs that hold two waves, not three.
+  const int lane = threadIdx.x & 63;
+  const int wave = vit_role(threadIdx.x >> 6);
+  const int tid = wave * 64 + lane;
+  if (ci.status == AFX_CLIP_NONFINITE || ci.T < 1) return;       // k_f0_backtrack writes the clip's (empty) results
   const ClipDesc cd = clips[clip];
-  if (ci.status == AFX_CLIP_NONFINITE || ci.T < 1) {
-    if (tid == 0) { st[0] = 0.0; st[1] = 0.0; st[2] = 1.0; st[3] = 0.0; }
-    if (out_f0) for (int t = tid; t < cd.tmax; t += kVitThreads) out_f0[f0_offsets[clip] + t] = (double)NAN;
-    return;
-  }
   const int T = ci.T, nb = fp.n_bins, S = 2 * nb, band = fp.band, width = 2 * band + 1;
   const VitLds L = vit_lds(fp);
   const int VM = nb + 2 * band;                                 // main cells per voicing (guards included)
@@ -727,8 +728,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
     gmax = bv; garg = bi;
   };
 
-  const double* LTs = LT;                               // stay
-  const double* LTw = LT + (size_t)width * width;       // switch
+  const double* LTs = LT;                               // stay (the switch table is k_f0_backtrack's business)
   // the interior row class (every source at least `band` bins from both range ends) is read through the scalar
   // cache: its index is wave-uniform, so the band walk's weights cost no LDS traffic and no vector registers
   cdouble_k* const kk = as_constant(tb.ltw);           // {stay, switch} per band entry, in walk order
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
     const int cnt = cand_cnt[ns];
     lu_ = cand_lu[ns];
     bin = -1; lp = 0.0;
-    if (tid < cnt) { bin = cand_bin[ns * fp.cap + tid]; lp = cand_lp[ns * fp.cap + tid]; }
+    if (tid < cnt && !(fp.debug & 128)) { bin = cand_bin[ns * fp.cap + tid]; lp = cand_lp[ns * fp.cap + tid]; }   // 128: timing only
   };
   int nx_bin; double nx_lp, nx_lu;
   load_cand(0, nx_bin, nx_lp, nx_lu);
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
       stamp(2);
       if (live) {
         put_value(vcur, jb, xv, xu);
-        vout[jb] = xv; vout[nb + jb] = xu;
+        if (!(fp.debug & 64)) { vout[jb] = xv; vout[nb + jb] = xu; }      // 64: timing only, no column stores
         note(xv, xu, jb, base == 0);
       }
     }
@@ -873,89 +873,225 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
     __syncthreads();
     stamp(5);
   }
-  // ---- last state, then back-tracking: the arg-max of the one state on the path, a step at a time
+  // ---- the last column's (max, first arg-max): where k_f0_backtrack starts
   double gmax; int garg;
   get_best(T & 1, gmax, garg);
-  uint16_t* sts = states + cd.frame_base;
-  __threadfence();
-  __syncthreads();
-  if (wave == 0) {
-    int cur = garg;
-    if (lane == 0) sts[T - 1] = (uint16_t)cur;
-    for (int t = T - 1; t >= 1; --t) {
-      const double* R = vclip + (size_t)(t - 1) * S;     // column t - 1
-      const VitBest gbst = bclip[t];                     // its maximum: the best out-of-band source
-      const bool tv = cur < nb;                          // target voiced?
-      const int jb = tv ? cur : cur - nb;
-      const int b = jb - band + lane;                    // this lane's source bin
-      const bool ok = lane < width && b >= 0 && b < nb;
-      double best = -INFINITY; int bi = 1 << 30;
-      if (ok) {
-        const int rc = b < band ? 1 + b : (b > nb - 1 - band ? 1 + band + (nb - 1 - b) : 0);
-        const int idx = rc * width + (2 * band - lane);  // entry jb - b + band of that row
-        const double ws = LTs[idx], ww = LTw[idx];
-        const double a0 = R[b], a1 = R[nb + b];
-        const double cv = a0 + (tv ? ws : ww), cu = a1 + (tv ? ww : ws);
-        best = cv; bi = b;                               // voiced sources come first (lower index)
-        if (cu > best) { best = cu; bi = nb + b; }
-      }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        const double ov = shfl_xor_d(best, o); const int oi = __shfl_xor(bi, o);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-      }
-      const int blo = jb - band < 0 ? 0 : jb - band, bhi = jb + band > nb - 1 ? nb - 1 : jb + band;
-      const int gb = gbst.arg >= nb ? gbst.arg - nb : gbst.arg;
-      if (gb < blo || gb > bhi) {
-        const double cand = gbst.value + c0;
-        if (cand > best || (cand == best && gbst.arg < bi)) { best = cand; bi = gbst.arg; }
-      }
-      cur = __builtin_amdgcn_readfirstlane(bi);
-      if (lane == 0) sts[t - 1] = (uint16_t)cur;
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
+  if (tid == 0) { VitBest vb; vb.value = gmax; vb.arg = garg; vb.pad = 0; bclip[0] = vb; }
   stamp(6);
   if constexpr (STAMP) {
     if (clip == 0 && lane == 0)
-      printf("vit wave %d T %d: top %llu best %llu walk %llu tail %llu partial %llu barrier %llu backtrack %llu\n", wave, T,
+      printf("vit wave %d T %d: top %llu best %llu walk %llu tail %llu partial %llu barrier %llu end %llu\n", wave, T,
              ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
   }
-  // ---- statistics over voiced frames (feature_extractor.py:97-107)
-  auto block_sum = [&](double v) -> double {
-    v = wave_sum_d(v);
-    if (lane == 0) redv[wave] = v;
-    __syncthreads();
-    double s = 0.0;
-    for (int w = 0; w < NW; ++w) s += redv[w];
-    __syncthreads();
-    return s;
-  };
-  double s1 = 0.0, c1 = 0.0;
-  for (int t = tid; t < T; t += kVitThreads) {
-    const int q = sts[t];
-    const bool voiced = q < nb;
-    const double f = tb.freqs[voiced ? q : q - nb];
-    if (voiced) { s1 += f; c1 += 1.0; }
-    if (out_f0) out_f0[f0_offsets[clip] + t] = voiced ? f : (double)NAN;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_f0_backtrack: the path through the value columns k_f0_viterbi left behind, then the statistics.
+// One wave per clip, four clips per workgroup.  A step is short (the first maximum over the 2 (2 band + 1) moves into
+// the one state on the path), but it cannot start before the step after it has named that state, and its operands --
+// 2 band + 1 cells of each half of one column -- are 9.6 KB apart from the previous step's, in HBM: inside
+// k_f0_viterbi's workgroup the walk cost one memory round trip per step (2.2 us, 1.9 ms per clip, with every other wave
+// of the workgroup and the CU's LDS waiting).  Here the columns come through an LDS-DMA ring D - 1 steps ahead of their
+// use: a move inside the band shifts the bin by at most `band`, so the window of +- (D - 1) band bins around the bin of
+// the step just decided holds whatever band the step D - 1 later will need -- unless the path takes an out-of-band
+// move in between, in which case that step reads its cells directly (and waits for them).  The ring is read with
+// opaque ds_read instructions: the compiler orders every LDS access it can see behind *all* outstanding LDS-DMA
+// (s_waitcnt vmcnt(0)), which would make the ring one slot deep.  For the same reason the loop has no other LDS
+// access and no other memory instruction: the per-column (max, arg-max) records and the states travel 64 steps at a
+// time through the lanes' registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBtWaves = 4;
+constexpr int kBtWin = 256;                       // doubles per half column in a ring slot: two 1 KB DMA instructions
+__host__ __device__ inline int f0_bt_depth(int band) { return 2 * band * 5 + 2 <= kBtWin ? 6 : 5; }
+size_t f0_backtrack_lds_bytes(const F0Params& fp) {
+  const size_t width = 2 * (size_t)fp.band + 1;
+  return (2 * width * width + 2 + (size_t)kBtWaves * (f0_bt_depth(fp.band) + 1) * 2 * kBtWin) * sizeof(double);
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+#pragma clang diagnostic pop
+}
+__device__ __forceinline__ double lds_read_opaque(unsigned addr) {      // complete after lds_wait_opaque()
+  double v;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_wait_opaque(double& a, double& b, double& c, double& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * kBtWaves) void k_f0_backtrack(const ClipDesc* __restrict__ clips,
+                                                                const ClipInfo* __restrict__ info, F0Tables tb,
+                                                                F0Params fp, const double* __restrict__ vrows,
+                                                                const VitBest* __restrict__ vbest,
+                                                                uint16_t* __restrict__ states,
+                                                                double* __restrict__ out_stats,
+                                                                double* __restrict__ out_f0,
+                                                                const int64_t* __restrict__ f0_offsets, int n_clips) {
+  extern __shared__ double smb[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = fp.n_bins, S = 2 * nb, band = fp.band, width = 2 * band + 1;
+  const int ltn = 2 * width * width;
+  for (int i = threadIdx.x; i < ltn; i += 64 * kBtWaves) smb[i] = tb.lt[i];
+  __syncthreads();                                                  // the only barrier: from here on the waves are on their own
+  const int clip = blockIdx.x * kBtWaves + wave;
+  if (clip >= n_clips) return;
+  const ClipInfo ci = info[clip];
+  const ClipDesc cd = clips[clip];
+  double* st = out_stats + (size_t)clip * 4;
+  if (ci.status == AFX_CLIP_NONFINITE || ci.T < 1) {
+    if (lane == 0) { st[0] = 0.0; st[1] = 0.0; st[2] = 1.0; st[3] = 0.0; }
+    if (out_f0) for (int t = lane; t < cd.tmax; t += 64) out_f0[f0_offsets[clip] + t] = (double)NAN;
+    return;
   }
-  if (out_f0) for (int t = T + tid; t < cd.tmax; t += kVitThreads) out_f0[f0_offsets[clip] + t] = (double)NAN;   // trimmed away
-  const double cntv = block_sum(c1);
-  const double sum = block_sum(s1);
+  const int T = ci.T;
+  const double c0 = fp.c0;
+  const double* const vclip = vrows + (size_t)cd.frame_base * S;
+  const VitBest* const bclip = vbest + cd.frame_base;
+  uint16_t* const sts = states + cd.frame_base;
+  double* const ring = smb + ((ltn + 1) & ~1) + (size_t)wave * (D + 1) * 2 * kBtWin;
+  const unsigned lt_a = lds_addr(smb), ring_a = lds_addr(ring);
+  const int HW = band * (D - 1);
+
+  // the window of a column around bin `cen`: each half starts at an even element of the column (16-byte DMA pieces)
+  auto win_lo = [&](int cen, int v) { int b0 = cen - HW; b0 = b0 < 0 ? 0 : b0; return (v * nb + b0) & ~1; };
+  auto prefetch = [&](int c, int cen) {                              // four DMA instructions, always
+    const int slot = c < 0 ? D : c % D;                              // past the first column: into the spare slot
+    const double* R = vclip + (size_t)(c < 0 ? 0 : c) * S;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const double* src = R + win_lo(cen, v) + 2 * lane;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 128 * i),
+                                         (__attribute__((address_space(3))) void*)(ring + (slot * 2 + v) * kBtWin + 128 * i),
+                                         16, 0, 0);
+    }
+  };
+
+  const VitBest last = bclip[0];                                     // (max, first arg-max) of column T - 1
+  int cur = last.arg;
+  int cens = 0;                                                      // lane s: the centre slot s was fetched around
+  {
+    const int j0 = cur < nb ? cur : cur - nb;
+    for (int k = 0; k < D - 1; ++k) {                                // columns T - 2 .. T - D
+      const int c = T - 2 - k;
+      prefetch(c, j0);
+      if (c >= 0) cens = (lane == (c % D) ? (j0) : cens);
+    }
+  }
+  int pend = 0;                                                      // lane i: the state of step t_hi - i, not yet stored
+  int t_hi = T - 1;
+  pend = (lane == (0) ? (cur) : pend);
+  double s1 = 0.0, c1 = 0.0;                                         // sum and count of the voiced frames' frequencies
+  auto tally = [&](int q) { if (q < nb) { s1 += tb.freqs[q]; c1 += 1.0; } };
+
+  for (int tb0 = T - 1; tb0 >= 1; tb0 -= 64) {                       // steps tb0, tb0 - 1, ... (64 at most)
+    const int ti = tb0 - lane;
+    double gv = 0.0; int ga = 0;
+    if (ti >= 1) { const VitBest vb = bclip[ti]; gv = vb.value; ga = vb.arg; }
+    int gvl = __double2loint(gv), gvh = __double2hiint(gv);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(gvl), "+v"(gvh), "+v"(ga)::"memory");     // here, not at the first use inside the loop
+    const int nsteps = tb0 < 64 ? tb0 : 64;
+    for (int k = 0; k < nsteps; ++k) {
+      const int t = tb0 - k, c = t - 1;                              // the move into state `cur` of frame t, out of column c
+      const double g_value = __hiloint2double(__builtin_amdgcn_readlane(gvh, k), __builtin_amdgcn_readlane(gvl, k));
+      const int g_arg = __builtin_amdgcn_readlane(ga, k);
+      const bool tv = cur < nb;
+      const int jb = tv ? cur : cur - nb;
+      const int b = jb - band + lane;                                // this lane's source bin
+      const bool ok = lane < width && b >= 0 && b < nb;
+      const int blo = jb - band < 0 ? 0 : jb - band, bhi = jb + band > nb - 1 ? nb - 1 : jb + band;
+      const int slot = c % D;
+      const int cen = __builtin_amdgcn_readlane(cens, slot);
+      const int w0 = win_lo(cen, 0), w1 = win_lo(cen, 1);
+      const bool hit = blo >= w0 && bhi - w0 < kBtWin && nb + blo >= w1 && nb + bhi - w1 < kBtWin;
+      const int bc = ok ? b : blo;                                   // idle lanes read somewhere harmless
+      const int rc = bc < band ? 1 + bc : (bc > nb - 1 - band ? 1 + band + (nb - 1 - bc) : 0);
+      const int idx = rc * width + (jb - bc + band);                 // entry jb - b + band of that row
+      double ws = lds_read_opaque(lt_a + 8u * (unsigned)idx);
+      double ww = lds_read_opaque(lt_a + 8u * (unsigned)(width * width + idx));
+      double a0, a1;
+      if (hit) {
+        // this column's four DMAs have landed once at most those of the D - 2 columns behind it are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 2)) : "memory");
+        a0 = lds_read_opaque(ring_a + 8u * (unsigned)((slot * 2 + 0) * kBtWin + (bc - w0)));
+        a1 = lds_read_opaque(ring_a + 8u * (unsigned)((slot * 2 + 1) * kBtWin + (nb + bc - w1)));
+      } else {
+        const double* R = vclip + (size_t)c * S;
+        a0 = R[bc]; a1 = R[nb + bc];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");   // on this path only
+      }
+      lds_wait_opaque(ws, ww, a0, a1);
+      double best = -INFINITY; int bi = 1 << 30;
+      if (ok) {
+        const double cv = a0 + (tv ? ws : ww), cu = a1 + (tv ? ww : ws);
+        best = cv; bi = b;                                           // voiced sources come first (lower index)
+        if (cu > best) { best = cu; bi = nb + b; }
+      }
+      {                                                              // (max, lowest index) over the wave
+        const double m = wave_max_dpp(best);
+        const unsigned long long at = __ballot(best == m);
+        if (__popcll(at) == 1) bi = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(at));
+        else bi = wave_min_dpp(best == m ? bi : (1 << 30));
+        best = m;
+      }
+      const int gb = g_arg >= nb ? g_arg - nb : g_arg;
+      if (gb < blo || gb > bhi) {                                    // the best out-of-band source
+        const double cand = g_value + c0;
+        if (cand > best || (cand == best && g_arg < bi)) { best = cand; bi = g_arg; }
+      }
+      cur = __builtin_amdgcn_readfirstlane(bi);
+      // the column D - 1 steps on, around the bin just decided
+      {
+        const int jn = cur < nb ? cur : cur - nb;
+        const int cn = c - (D - 1);
+        prefetch(cn, jn);
+        if (cn >= 0) cens = (lane == (cn % D) ? (jn) : cens);
+      }
+      // state of frame t - 1: into the pending register, flushed 64 at a time
+      const int pos = t_hi - (t - 1);
+      if (pos == 64) {
+        const int q = pend;                                          // lane i: frame t_hi - i
+        sts[t_hi - lane] = (uint16_t)q;
+        tally(q);
+        t_hi -= 64;
+        pend = (lane == (0) ? (cur) : pend);
+      } else {
+        pend = (lane == (pos) ? (cur) : pend);
+      }
+    }
+  }
+  {                                                                  // frames t_hi .. 0 are still pending
+    const int q = pend;
+    if (lane <= t_hi) { sts[t_hi - lane] = (uint16_t)q; tally(q); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __threadfence_block();
+
+  // ---- statistics over voiced frames (feature_extractor.py:97-107)
+  if (out_f0) {
+    for (int t = lane; t < T; t += 64) { const int q = sts[t]; out_f0[f0_offsets[clip] + t] = q < nb ? tb.freqs[q] : (double)NAN; }
+    for (int t = T + lane; t < cd.tmax; t += 64) out_f0[f0_offsets[clip] + t] = (double)NAN;      // trimmed away
+  }
+  const double cntv = wave_sum_d(c1);
+  const double sum = wave_sum_d(s1);
   if (cntv > 0.0) {
     const double mean = sum / cntv;
     double s2 = 0.0;
-    for (int t = tid; t < T; t += kVitThreads) {
+    for (int t = lane; t < T; t += 64) {
       const int q = sts[t];
       if (q < nb) { const double d = tb.freqs[q] - mean; s2 += d * d; }
     }
-    const double var = block_sum(s2) / cntv;
-    if (tid == 0) {
+    const double var = wave_sum_d(s2) / cntv;
+    if (lane == 0) {
       const double missing = ((double)T - cntv) / (double)T;
       st[0] = mean; st[1] = sqrt(var); st[2] = missing; st[3] = 1.0 - missing;
     }
-  } else if (tid == 0) {
+  } else if (lane == 0) {
     st[0] = 0.0; st[1] = 0.0; st[2] = 1.0; st[3] = 0.0;
   }
 }
@@ -1045,6 +1181,24 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
   return hipGetLastError();
 }
 
+static hipError_t launch_f0_backtrack(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const F0Tables& tb,
+                                      const F0Params& fp, const double* vrows, const VitBest* vbest, uint16_t* states,
+                                      double* out_stats, double* out_f0, const int64_t* f0_offsets, int n_clips) {
+  const size_t lds = f0_backtrack_lds_bytes(fp);
+  const dim3 grid((n_clips + kBtWaves - 1) / kBtWaves), block(64 * kBtWaves);
+  hipError_t e;
+  if (f0_bt_depth(fp.band) == 6) {
+    if ((e = allow_lds(k_f0_backtrack<6>, lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_f0_backtrack<6>, grid, block, lds, s, clips, info, tb, fp, vrows, vbest, states, out_stats, out_f0,
+                       f0_offsets, n_clips);
+  } else {
+    if ((e = allow_lds(k_f0_backtrack<5>, lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_f0_backtrack<5>, grid, block, lds, s, clips, info, tb, fp, vrows, vbest, states, out_stats, out_f0,
+                       f0_offsets, n_clips);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const F0Tables& tb,
                              const F0Params& fp, const int32_t* cand_cnt, const double* cand_vp,
                              const int16_t* cand_bin, const double* cand_prob, double* cand_lp, double* cand_lu,
@@ -1058,14 +1212,16 @@ hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInf
     hipError_t e = allow_lds(k_f0_viterbi<true>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_f0_viterbi<true>, dim3(n_clips), dim3(kVitThreads), lds, s, clips, info, tb, fp, cand_cnt,
-                       cand_bin, cand_lp, cand_lu, vrows, vbest, states, out_stats, out_f0, f0_offsets);
-    return hipGetLastError();
+                       cand_bin, cand_lp, cand_lu, vrows, vbest);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return launch_f0_backtrack(s, clips, info, tb, fp, vrows, vbest, states, out_stats, out_f0, f0_offsets, n_clips);
   }
   hipError_t e = allow_lds(k_f0_viterbi<false>, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_f0_viterbi<false>, dim3(n_clips), dim3(kVitThreads), lds, s, clips, info, tb, fp, cand_cnt,
-                     cand_bin, cand_lp, cand_lu, vrows, vbest, states, out_stats, out_f0, f0_offsets);
-  return hipGetLastError();
+                     cand_bin, cand_lp, cand_lu, vrows, vbest);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return launch_f0_backtrack(s, clips, info, tb, fp, vrows, vbest, states, out_stats, out_f0, f0_offsets, n_clips);
 }
 
 }  // namespace afx
