@@ -83,6 +83,13 @@ __device__ __forceinline__ int wave_min_dpp(int v) {               // uniform re
              min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+__device__ __forceinline__ void lds_fmax(double* p, double v) {      // *p = max(*p, v) in LDS, no return value
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  __hip_atomic_fetch_max((__attribute__((address_space(3))) double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma clang diagnostic pop
+}
+
 typedef const double __attribute__((address_space(4))) cdouble_k;   // constant address space: uniform reads become s_load
 __device__ __forceinline__ cdouble_k* as_constant(const double* p) {
 #pragma clang diagnostic push
@@ -610,18 +617,19 @@ __device__ __forceinline__ int vit_role(int hw) {       // hardware wave -> the 
   return (int)((roles >> (4 * hw)) & 15);
 }
 
-struct VitLds { size_t v, olp, lt, red, total; };
-__host__ __device__ inline VitLds vit_lds(const F0Params& fp) {
-  const size_t S = 2 * (size_t)fp.n_bins, width = 2 * (size_t)fp.band + 1;
+struct VitLds { size_t v, olp, lt, red, edge, total; };
+__host__ __device__ inline VitLds vit_lds(int n_bins, int band_) {
+  const size_t S = 2 * (size_t)n_bins, width = 2 * (size_t)band_ + 1;
   VitLds L;
   L.v = 0;                                   // two value columns of 2 (n_bins + 2 band) + 4 band doubles
-  L.olp = 2 * (S + 8 * fp.band);             // 3 n_bins doubles
-  L.lt = L.olp + 3 * fp.n_bins;              // 2 * width * width doubles
-  L.red = L.lt + 2 * width * width;          // 32 doubles + 32 ints (16 doubles): two sets of per-wave partials
-  L.total = (L.red + 48) * sizeof(double);
+  L.olp = 2 * (S + 8 * band_);               // 3 n_bins doubles
+  L.lt = L.olp + 3 * n_bins;                 // width * width doubles: the `stay` rows (k_f0_backtrack holds both tables)
+  L.red = L.lt + width * width;              // 32 doubles + 32 ints (16 doubles): two sets of per-wave partials
+  L.edge = L.red + 48;                       // per wave 4 x 2 band doubles (its best edge-class move per range-end target); 2 counters
+  L.total = (L.edge + (size_t)(kVitThreads / 64) * 8 * band_ + 2) * sizeof(double);
   return L;
 }
-size_t f0_viterbi_lds_bytes(const F0Params& fp) { return vit_lds(fp).total; }
+size_t f0_viterbi_lds_bytes(const F0Params& fp) { return vit_lds(fp.n_bins, fp.band).total; }
 
 // k_f0_logs: the log observation values the Viterbi pass scatters -- log(p + tiny) per candidate and the unvoiced
 // bins' common log((1 - voiced_prob) / n_bins + tiny) -- one wave per frame slot.  Kept out of the Viterbi step
@@ -638,7 +646,10 @@ __global__ __launch_bounds__(256) void k_f0_logs(const int32_t* __restrict__ can
   if (lane == 0) cand_lu[f] = log((1.0 - cand_vp[f]) / (double)fp.n_bins + fp.tiny);
 }
 
-template <bool STAMP>
+// MODE 0: production; 1: the timing-only ablation bits of AFX_F0_DEBUG honoured; 2: per-phase cycle stamps as well.
+// NBT / BANDT: n_bins and band compiled in (0: taken from the parameters) -- the step loop is short of scalar registers,
+// and with the reference's shape (601 bins, band 25) as constants the column strides and table offsets are immediates.
+template <int MODE, int NBT, int BANDT>
 __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* __restrict__ clips,
                                                                const ClipInfo* __restrict__ info,
                                                                F0Tables tb, F0Params fp,
@@ -654,7 +665,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   // AFX_F0_DEBUG & 16: per-phase cycle counts of workgroup 0, printed per wave (developer aid)
   unsigned long long ph[8] = {}, ph_t = 0;
   auto stamp = [&](int i) {
-    if constexpr (STAMP) {
+    if constexpr (MODE == 2) {
       __builtin_amdgcn_sched_barrier(0);
       const unsigned long long now = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -673,8 +684,9 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   const int tid = wave * 64 + lane;
   if (ci.status == AFX_CLIP_NONFINITE || ci.T < 1) return;       // k_f0_backtrack writes the clip's (empty) results
   const ClipDesc cd = clips[clip];
-  const int T = ci.T, nb = fp.n_bins, S = 2 * nb, band = fp.band, width = 2 * band + 1;
-  const VitLds L = vit_lds(fp);
+  const int T = ci.T, nb = NBT ? NBT : fp.n_bins, S = 2 * nb, band = BANDT ? BANDT : fp.band, width = 2 * band + 1;
+  const int dbg = MODE ? fp.debug : 0;
+  const VitLds L = vit_lds(nb, band);
   const int VM = nb + 2 * band;                                 // main cells per voicing (guards included)
   const int VS = 2 * VM + 4 * band;                             // doubles per value column: main[2], edge[2]
   double* const vbuf = smv + L.v;
@@ -684,13 +696,16 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   double* LT = smv + L.lt;
   double* redv = smv + L.red;
   int* redi = reinterpret_cast<int*>(redv + 32);
+  double* const ebuf = smv + L.edge;                            // [wave][low | high][voiced | unvoiced][2 band]
+  int* const ecnt = reinterpret_cast<int*>(ebuf + NW * 8 * band);   // waves that have delivered their share
   const double c0 = fp.c0;
   double* const vclip = vrows + (size_t)cd.frame_base * S;      // this clip's value columns, row t at t * S
   VitBest* const bclip = vbest + cd.frame_base;                 // (max, first argmax) of column t - 1 at [t]
 
-  for (int i = tid; i < 2 * width * width; i += kVitThreads) LT[i] = tb.lt[i];
+  for (int i = tid; i < width * width; i += kVitThreads) LT[i] = tb.lt[i];
   for (int i = tid; i < 3 * nb; i += kVitThreads) olp3[i] = c0;
   for (int i = tid; i < 2 * VS; i += kVitThreads) vbuf[i] = -INFINITY;      // guards and edge-class cells stay -inf
+  if (tid < 2) ecnt[tid] = 0;
   const double lpi_u = log(1.0 / (double)nb + fp.tiny);
 
   // (max value, lowest index) over the wave of a per-lane (value, index): DPP butterflies, no LDS round trips
@@ -762,7 +777,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
     const int cnt = cand_cnt[ns];
     lu_ = cand_lu[ns];
     bin = -1; lp = 0.0;
-    if (tid < cnt && !(fp.debug & 128)) { bin = cand_bin[ns * fp.cap + tid]; lp = cand_lp[ns * fp.cap + tid]; }   // 128: timing only
+    if (tid < cnt && !(dbg & 128)) { bin = cand_bin[ns * fp.cap + tid]; lp = cand_lp[ns * fp.cap + tid]; }   // 128: timing only
   };
   int nx_bin; double nx_lp, nx_lu;
   load_cand(0, nx_bin, nx_lp, nx_lu);
@@ -807,6 +822,32 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
     const double* m1 = vprev + VM;                       // folded for unvoiced targets
     const double* e0 = vprev + 2 * VM;                   // edge-class sources
     const double* e1 = e0 + 2 * band;
+    // ---- the edge-class sources' moves, every wave a share (one pass over the range: `single`).  The 2 band sources
+    // next to a range end have a transition row of their own each, and the 2 band targets they reach were two waves'
+    // business: 2 band extra passes of ten instructions on top of a walk of 2 band + 1 entries, with eight waves
+    // waiting at the barrier.  Now wave w takes sources w, w + NW, ...: lane j forms the move into range-end target j
+    // (the row is uniform; a lane out of the source's band reads a log(0) cell), the wave's best goes into its row of
+    // an LDS array, and the wave that owns the targets takes the maximum over the rows behind its own walk -- by then
+    // the others have long delivered (it checks a counter).  max is exact and order-free: the same values as before.
+    // (ds_max_f64 into one shared row was tried first: 3.4 ms slower than no sharing, the atomics serialise.)
+    const bool share_edges = single && t > 0 && !(dbg & 4) && !(dbg & 256);      // 256: the owners' own passes (A/B)
+    if (share_edges) {
+      double lv = -INFINITY, lu_ = -INFINITY, hv = -INFINITY, hu = -INFINITY;
+      for (int p = wave; p < 2 * band; p += NW) {
+        const bool low = p < band;
+        const int k = low ? p : p - band;
+        const int d = low ? lane - k + band : lane - k;          // jb - b + band, jb = lane | nb - 2 band + lane
+        const int rc = low ? 1 + k : 2 * band - k;
+        const double ws = LTs[(unsigned)d <= (unsigned)(2 * band) ? rc * width + d : width];
+        const double sv = e0[p] + ws, su = e1[p] + ws;
+        if (low) { lv = fmax(lv, sv); lu_ = fmax(lu_, su); } else { hv = fmax(hv, sv); hu = fmax(hu, su); }
+      }
+      if (lane < 2 * band) {
+        double* const mine = ebuf + wave * 8 * band + lane;
+        mine[0] = lv; mine[2 * band] = lu_; mine[4 * band] = hv; mine[6 * band] = hu;
+      }
+      if (lane == 0) __hip_atomic_fetch_add(ecnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     for (int base = 0; base < nb; base += kVitThreads) {
       int jb = base + tid;
       bool live = jb < nb;
@@ -821,7 +862,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
         xv = olp[jc] + c0; xu = lu + lpi_u;
       } else {
         double bv = -INFINITY, bu = -INFINITY;           // best move into (voiced jb), (unvoiced jb)
-        if (!(fp.debug & 1)) {
+        if (!(dbg & 1)) {
           const double* p0 = m0 + jc;                    // cells of the sources jc - band .. jc + band
           const double* p1 = m1 + jc;
 #pragma unroll 4
@@ -840,7 +881,20 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
             bv = fmax(bv, e0[k] + ws);
             bu = fmax(bu, e1[k] + ws);
           };
-          if (!(fp.debug & 4)) {
+          if (share_edges) {
+            const bool lo_owner = wave == 0, hi_owner = wave == NW - 1;
+            if (lo_owner || hi_owner) {
+              // the counter runs on: NW more per step (t = 1 is the first step with shares)
+              while (__hip_atomic_load(ecnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * t) __builtin_amdgcn_s_sleep(1);
+              const int jr = lo_owner ? lane : lane - (64 - 2 * band);      // target index within the range end
+              const int j = jr < 0 ? 0 : (jr >= 2 * band ? 2 * band - 1 : jr);   // (the wave's other lanes read along)
+              const double* eb = ebuf + (hi_owner ? 4 * band : 0) + j;
+              double ev = -INFINITY, eu = -INFINITY;
+#pragma unroll
+              for (int w = 0; w < NW; ++w) { ev = fmax(ev, eb[w * 8 * band]); eu = fmax(eu, eb[w * 8 * band + 2 * band]); }
+              if (jr == j) { bv = fmax(bv, ev); bu = fmax(bu, eu); }
+            }
+          } else if (!(dbg & 4)) {
             if (__any(live && jb < 2 * band)) {
 #pragma unroll 5
               for (int b = 0; b < band; ++b) edge_pass(b, b, 1 + b);
@@ -861,7 +915,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
       stamp(2);
       if (live) {
         put_value(vcur, jb, xv, xu);
-        if (!(fp.debug & 64)) { vout[jb] = xv; vout[nb + jb] = xu; }      // 64: timing only, no column stores
+        if (!(dbg & 64)) { vout[jb] = xv; vout[nb + jb] = xu; }      // 64: timing only, no column stores
         note(xv, xu, jb, base == 0);
       }
     }
@@ -878,7 +932,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   get_best(T & 1, gmax, garg);
   if (tid == 0) { VitBest vb; vb.value = gmax; vb.arg = garg; vb.pad = 0; bclip[0] = vb; }
   stamp(6);
-  if constexpr (STAMP) {
+  if constexpr (MODE == 2) {
     if (clip == 0 && lane == 0)
       printf("vit wave %d T %d: top %llu best %llu walk %llu tail %llu partial %llu barrier %llu end %llu\n", wave, T,
              ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
@@ -1208,18 +1262,19 @@ hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInf
   hipLaunchKernelGGL(k_f0_logs, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, s, cand_cnt, cand_vp, cand_prob, cand_lp,
                      cand_lu, frames, fp);
   const size_t lds = f0_viterbi_lds_bytes(fp);
-  if (fp.debug & 16) {
-    hipError_t e = allow_lds(k_f0_viterbi<true>, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_f0_viterbi<true>, dim3(n_clips), dim3(kVitThreads), lds, s, clips, info, tb, fp, cand_cnt,
-                       cand_bin, cand_lp, cand_lu, vrows, vbest);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    return launch_f0_backtrack(s, clips, info, tb, fp, vrows, vbest, states, out_stats, out_f0, f0_offsets, n_clips);
-  }
-  hipError_t e = allow_lds(k_f0_viterbi<false>, lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_f0_viterbi<false>, dim3(n_clips), dim3(kVitThreads), lds, s, clips, info, tb, fp, cand_cnt,
-                     cand_bin, cand_lp, cand_lu, vrows, vbest);
+  hipError_t e;
+#define AFX_VIT_LAUNCH(MODE, NBT, BANDT)                                                                              \
+  do {                                                                                                               \
+    if ((e = allow_lds(k_f0_viterbi<MODE, NBT, BANDT>, lds)) != hipSuccess) return e;                                \
+    hipLaunchKernelGGL((k_f0_viterbi<MODE, NBT, BANDT>), dim3(n_clips), dim3(kVitThreads), lds, s, clips, info, tb, fp, \
+                       cand_cnt, cand_bin, cand_lp, cand_lu, vrows, vbest);                                          \
+  } while (0)
+  const bool ref_shape = fp.n_bins == 601 && fp.band == 25;       // fmin / fmax of the reference at hop / sr = 256 / 22050, 512 / 44100
+  if (fp.debug & 16) AFX_VIT_LAUNCH(2, 0, 0);
+  else if (fp.debug) { if (ref_shape) AFX_VIT_LAUNCH(1, 601, 25); else AFX_VIT_LAUNCH(1, 0, 0); }
+  else if (ref_shape) AFX_VIT_LAUNCH(0, 601, 25);
+  else AFX_VIT_LAUNCH(0, 0, 0);
+#undef AFX_VIT_LAUNCH
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return launch_f0_backtrack(s, clips, info, tb, fp, vrows, vbest, states, out_stats, out_f0, f0_offsets, n_clips);
 }
