@@ -14,6 +14,15 @@ for i in range(n // 2):                                  # voiced material: vibr
     f = float(rng.uniform(80, 900))
     ph = 2 * np.pi * np.cumsum(f * (1 + 0.02 * np.sin(2 * np.pi * rng.uniform(3, 7) * t))) / 22050
     clips.append((0.3 * np.sin(ph) + 0.1 * np.sin(2 * ph) + 0.05 * np.sin(3 * ph) + rng.uniform(0.001, 0.05) * rng.standard_normal(t.size)).astype(np.float32))
+# the range ends (edge-class transition rows), silence (the path sits in bin 0), and pitch jumps far out of the transition
+# band (out-of-band moves: k_f0_backtrack's direct reads)
+for f in (65.5, 66.0, 68.0, 72.0, 80.0, 1800.0, 1950.0, 2050.0, 2090.0):
+    clips.append((0.4 * np.sin(2 * np.pi * f * t) + 0.002 * rng.standard_normal(t.size)).astype(np.float32))
+clips.append(np.zeros(t.size, np.float32))
+clips.append((1e-4 * rng.standard_normal(t.size)).astype(np.float32))
+for (fa, fb, seg) in ((100.0, 1500.0, 0.1), (70.0, 2000.0, 0.05), (300.0, 310.0, 0.2), (90.0, 700.0, 0.03)):
+    fi = np.where((np.floor(t / seg).astype(int) & 1) == 0, fa, fb)
+    clips.append((0.4 * np.sin(2 * np.pi * np.cumsum(fi) / 22050) + 0.002 * rng.standard_normal(t.size)).astype(np.float32))
 lengths = np.array([c.size for c in clips], np.int64)
 pad = (lengths + 3) // 4 * 4
 offsets = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.int64)
