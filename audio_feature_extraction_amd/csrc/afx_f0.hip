@@ -791,6 +791,20 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   // targets of this thread: bin tid (+ a multiple of the block size); when one pass covers the range, the last
   // wave takes the top 64 bins so that the high-edge targets share one wave
   const bool single = nb <= kVitThreads && nb >= 128;
+  // the weights of this wave's share of the edge-class moves (below): lane j's entry of the row of source w + i NW
+  constexpr int kShare = BANDT > 0 ? (2 * BANDT + NW - 1) / NW : 1;
+  double wsh[kShare];
+  if constexpr (BANDT > 0) {
+#pragma unroll
+    for (int i = 0; i < kShare; ++i) {
+      const int p = wave + i * NW;
+      const bool low = p < band;
+      const int k = low ? p : p - band;
+      const int d = low ? lane - k + band : lane - k;            // jb - b + band, jb = lane | nb - 2 band + lane
+      const int rc = low ? 1 + k : 2 * band - k;
+      wsh[i] = p < 2 * band ? LTs[(unsigned)d <= (unsigned)(2 * band) ? rc * width + d : width] : 0.0;
+    }
+  }
   for (int t = 0; t < T; ++t) {
     stamp(-1);
     const double* olp = olp3 + (t % 3) * nb;
@@ -833,6 +847,16 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
     const bool share_edges = single && t > 0 && !(dbg & 4) && !(dbg & 256);      // 256: the owners' own passes (A/B)
     if (share_edges) {
       double lv = -INFINITY, lu_ = -INFINITY, hv = -INFINITY, hu = -INFINITY;
+      if constexpr (BANDT > 0) {                                   // this wave's sources and their weights never change
+#pragma unroll
+        for (int i = 0; i < kShare; ++i) {
+          const int p = wave + i * NW;
+          if (p < 2 * band) {
+            const double sv = e0[p] + wsh[i], su = e1[p] + wsh[i];
+            if (p < band) { lv = fmax(lv, sv); lu_ = fmax(lu_, su); } else { hv = fmax(hv, sv); hu = fmax(hu, su); }
+          }
+        }
+      } else {
       for (int p = wave; p < 2 * band; p += NW) {
         const bool low = p < band;
         const int k = low ? p : p - band;
@@ -841,6 +865,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
         const double ws = LTs[(unsigned)d <= (unsigned)(2 * band) ? rc * width + d : width];
         const double sv = e0[p] + ws, su = e1[p] + ws;
         if (low) { lv = fmax(lv, sv); lu_ = fmax(lu_, su); } else { hv = fmax(hv, sv); hu = fmax(hu, su); }
+      }
       }
       if (lane < 2 * band) {
         double* const mine = ebuf + wave * 8 * band + lane;
