@@ -61,7 +61,9 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {       // s
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 
-#define F0_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, false)
+// quad_perm / row_mirror / row_half_mirror only: every lane has a source, so bound_ctrl changes nothing but spares the
+// v_mov_b32 that would otherwise initialise the destination with the `old` value
+#define F0_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, true)
 template <int CTRL> __device__ __forceinline__ double dpp_dd(double v) {
   return __hiloint2double(F0_DPP_I(__double2hiint(v), CTRL), F0_DPP_I(__double2loint(v), CTRL));
 }
