@@ -92,6 +92,15 @@ __device__ __forceinline__ void lds_fmax(double* p, double v) {      // *p = max
 #pragma clang diagnostic pop
 }
 
+// max of two doubles that are never NaN, as the one instruction it is: fmax() makes the compiler quiet a possible signalling
+// NaN in every operand whose origin it cannot see (a v_max_f64 x, x, x in front of the real one -- for values read from LDS,
+// moved by DPP, or merged from two branches)
+__device__ __forceinline__ double max_nn(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 typedef const double __attribute__((address_space(4))) cdouble_k;   // constant address space: uniform reads become s_load
 __device__ __forceinline__ cdouble_k* as_constant(const double* p) {
 #pragma clang diagnostic push
@@ -855,7 +864,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
           const int p = wave + i * NW;
           if (p < 2 * band) {
             const double sv = e0[p] + wsh[i], su = e1[p] + wsh[i];
-            if (p < band) { lv = fmax(lv, sv); lu_ = fmax(lu_, su); } else { hv = fmax(hv, sv); hu = fmax(hu, su); }
+            if (p < band) { lv = max_nn(lv, sv); lu_ = max_nn(lu_, su); } else { hv = max_nn(hv, sv); hu = max_nn(hu, su); }
           }
         }
       } else {
@@ -918,8 +927,8 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
               const double* eb = ebuf + (hi_owner ? 4 * band : 0) + j;
               double ev = -INFINITY, eu = -INFINITY;
 #pragma unroll
-              for (int w = 0; w < NW; ++w) { ev = fmax(ev, eb[w * 8 * band]); eu = fmax(eu, eb[w * 8 * band + 2 * band]); }
-              if (jr == j) { bv = fmax(bv, ev); bu = fmax(bu, eu); }
+              for (int w = 0; w < NW; ++w) { ev = max_nn(ev, eb[w * 8 * band]); eu = max_nn(eu, eb[w * 8 * band + 2 * band]); }
+              if (jr == j) { bv = max_nn(bv, ev); bu = max_nn(bu, eu); }
             }
           } else if (!(dbg & 4)) {
             if (__any(live && jb < 2 * band)) {
