@@ -10,8 +10,10 @@
 //                 parabolic refinement, pitch bins -> a sparse observation column per frame
 //   k_f0_logs     the log observation values the Viterbi pass scatters (kept out of its step loop)
 //   k_f0_viterbi  one workgroup per clip: log-domain Viterbi over 2 x n_bins states with the banded
-//                 transition matrix -- value-only forward pass, one barrier per step, the arg-max
-//                 recomputed along the path while back-tracking -- and the f0 statistics
+//                 transition matrix -- value-only forward pass, one barrier per step, every value
+//                 column kept
+//   k_f0_backtrack one wave per clip: the arg-max recomputed along the path through the kept columns
+//                 (an LDS-DMA ring runs five steps ahead of it), then the f0 statistics
 //                 (feature_extractor.py:97-114)
 // A wave issues one instruction per ~9 ticks on this part however many waves share its SIMD
 // (tools/micro/f64_rate.hip): these kernels are bound by the instruction count of their longest wave,
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
 // Back-pointers are not formed in the forward pass.  Back-tracking visits one state per step, so only T of
 // the T x 2 n_bins arg-maxima are ever used: the forward pass keeps the *values* (add + max per band entry,
 // half the instructions of a running arg-max and no index registers, which is what lets two workgroups
-// share a CU) and writes every value column to HBM (2 n_bins doubles per frame); the backward pass then
+// share a CU) and writes every value column to HBM (2 n_bins doubles per frame); the backward pass (k_f0_backtrack) then
 // recomputes, for the one state on the path, the same sums in the same order and takes their first maximum
 // (numpy's argmax rule) -- bit-identical to forming all pointers up front.
 // ---------------------------------------------------------------------------------------------
