@@ -26,7 +26,6 @@ from .. import _native, wavio
 _C2_HZ = 65.40639132514966
 _C7_HZ = 2093.004522404789
 
-_MAX_BATCH_SAMPLES = 192 * 1024 * 1024     # per device sub-batch (768 MB of float32)
 
 
 def _status_error(status: int, what: str, n_frames: int = 0) -> Exception:

@@ -111,6 +111,30 @@ class _PinPool:
             self.free.append(b)
 
 
+class _DevPool:
+    """The HBM window buffer of one (device, lane) worker, kept across windows and calls (a worker has one window on the
+    device at a time).  hipMalloc / hipFree per window cost more than their own time: a free synchronises the whole device,
+    i.e. also the passes the other workers have in flight."""
+
+    def __init__(self, plan):
+        self.plan, self.buf, self.lock = plan, None, threading.Lock()
+
+    def get(self, nbytes: int):
+        with self.lock:
+            b, self.buf = self.buf, None
+        if b is not None and getattr(b, "nbytes", 0) >= nbytes:
+            return b
+        if b is not None:
+            b.free()
+        return self.plan.device_buffer(max(int(nbytes * 1.25), 16))
+
+    def put(self, b):
+        with self.lock:
+            old, self.buf = self.buf, b
+        if old is not None:
+            old.free()
+
+
 LAST_TIMING: Dict[str, Any] = {}     # seconds per phase of the last process_files call (developer aid)
 WORKERS_PER_GPU = 3     # sub-batches in flight per GPU (own context / stream / thread): copies, the bandwidth-bound
                         # kernels and the host round trip of one hide under the frame kernel of another
@@ -119,14 +143,20 @@ DECODE_THREADS_PER_GPU = 16
 
 def _windows(sizes: Sequence[int], idxs: Sequence[int], budget: int) -> List[List[int]]:
     """Cuts a lane's files (in order) into windows whose estimated sample count stays under ``budget``;
-    a single file larger than the budget is a window of its own."""
+    a single file larger than the budget is a window of its own.  The windows are of even size -- as many as the budget
+    demands, each an even share of the lane's samples: a short last window costs a whole device pass (the pYIN pass of 30
+    clips takes as long as that of 300: its Viterbi kernel is 862 dependent steps whatever the number of clips)."""
+    total = sum(int(sizes[i]) for i in idxs)
+    nwin = max(1, -(-total // max(int(budget), 1)))
+    share = total / nwin
     out: List[List[int]] = []
     cur: List[int] = []
-    tot = 0
+    tot = done = 0
     for i in idxs:
         sz = int(sizes[i])
-        if cur and tot + sz > budget:
+        if cur and (tot + sz > budget or (done + tot >= share * (len(out) + 1) and len(out) + 1 < nwin)):
             out.append(cur)
+            done += tot
             cur, tot = [], 0
         cur.append(i)
         tot += sz
@@ -153,7 +183,7 @@ def normalize_features(features_to_extract) -> Tuple[str, ...]:
     return tuple(g for g in FEATURE_GROUPS if g in req)
 
 
-def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 1024 * 1024,
+def process_files(extractor, files: Sequence, max_batch_samples: int = 80 * 1024 * 1024,
                   workers_per_gpu: int = WORKERS_PER_GPU, features_to_extract=None) -> List[Dict[str, Any]]:
     """Shard over GPUs (and over a few workers per GPU) -> per worker a pipeline of bounded windows:
     decode window k + 1 on the shared host pool while window k is packed, uploaded and extracted ->
@@ -254,11 +284,15 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
         decoded = list(pool.map(dec, rest)) if rest else []
         return packed, rest, decoded
 
-    def run_group(plans, cur, buf, offs, lens, fmt):
+    timeline: List[Any] = []                                      # (lane, clips, t_begin, t_uploaded, t_f0_done, t_collected) per sub-batch
+
+    def run_group(plans, cur, buf, offs, lens, fmt, dev):
         plan, plan_f0 = plans
-        dbuf = plan.device_buffer(max(buf.nbytes, 16))            # one PCIe copy for both passes
+        tl = [None, len(cur), time.perf_counter() - t_start, 0.0, 0.0, 0.0]
+        dbuf = dev.get(max(buf.nbytes, 16))                       # one PCIe copy for both passes
         try:
             dbuf.upload(buf)
+            tl[3] = time.perf_counter() - t_start
             submitted = False
             if want_stats:                                        # MFCC / RMS pass: queued, runs beside the pYIN pass below
                 plan.extract_submit(dbuf, offs, lens, flags=flags, fmt=fmt)
@@ -267,9 +301,12 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
             try:
                 if want_f0:
                     f0 = plan_f0.f0_batch(dbuf, offs, lens, extractor.f0_min, extractor.f0_max, flags=flags, fmt=fmt)
+                tl[4] = time.perf_counter() - t_start
             finally:
                 if submitted:                                     # always: the buffer must outlive the queued pass
                     out = plan.extract_collect()
+            tl[5] = time.perf_counter() - t_start
+            timeline.append(tl)
             nsamp[cur] = lens
             if out is not None:
                 stats[cur] = out["stats"]
@@ -281,14 +318,16 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
             # status (non-finite input) decides
             status[cur] = out["status"] if out is not None else f0["status"]
         finally:
-            dbuf.free()
+            dev.put(dbuf)                                         # both passes are through (collect above): reusable
 
     def worker(lane, idxs):
         wins = _windows(sizes, idxs, max_batch_samples)
-        plan = pin = None
+        plan = pin = dev = None
         try:                                                      # (MFCC / RMS plan, pYIN plan): own context and stream each
             plan = (extractor._plan(lane[0], lane[1]),
                     extractor._plan(lane[0], (lane[1], "f0")) if want_f0 else None)
+            dpools = extractor.__dict__.setdefault("_dev_pools", {})
+            dev = dpools.get(lane) or dpools.setdefault(lane, _DevPool(plan[0]))
             if hasattr(plan[0], "pinned_buffer"):                 # page-locked window buffers, kept with the extractor
                 pools = extractor.__dict__.setdefault("_pin_pools", {})
                 pin = pools.get(lane) or pools.setdefault(lane, _PinPool(plan[0]))
@@ -314,7 +353,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
                             end += 1
                         lo = int(offs[pos])
                         hi = int(offs[end - 1] + (lens[end - 1] + 3) // 4 * 4)
-                        run_group(plan, ids[pos:end], buf[lo:hi], offs[pos:end] - lo, lens[pos:end], _native.FMT_S16)
+                        run_group(plan, ids[pos:end], buf[lo:hi], offs[pos:end] - lo, lens[pos:end], _native.FMT_S16, dev)
                         pos = end
                 for kind, fmt, dt in (("s16", _native.FMT_S16, np.int16), ("f32", _native.FMT_F32, np.float32)):
                     sel = [(i, d[1]) for i, d in zip(rest, decoded) if d is not None and d[0] == kind]
@@ -325,7 +364,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
                             tot += sel[end][1].size
                             end += 1
                         buf, offs, lens = _pack([y for _, y in sel[pos:end]], dt)
-                        run_group(plan, [i for i, _ in sel[pos:end]], buf, offs, lens, fmt)
+                        run_group(plan, [i for i, _ in sel[pos:end]], buf, offs, lens, fmt, dev)
                         pos = end
             except Exception as e:          # a device-level failure drops the files of the sub-batch it hit, and the
                 for i in win:               # rest of this window; later windows are still attempted
@@ -372,5 +411,5 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 192 * 102
         results.append(rec)
         log.info(f"成功處理文件: {name}")
     LAST_TIMING.update(pipeline=t_gpu - t_start, decode_wait=phase["decode_wait"], device=phase["device"],
-                       dicts=time.perf_counter() - t_gpu, files=n, workers=len(threads))
+                       dicts=time.perf_counter() - t_gpu, files=n, workers=len(threads), timeline=sorted(timeline, key=lambda r: r[2]))
     return results

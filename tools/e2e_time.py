@@ -27,7 +27,10 @@ for win in wins:
     frames = n * (1 + int(22050 * dur) // 256)
     print(f"batch_process: {len(out)} files of {dur:.0f} s in {dt*1e3:.0f} ms = {len(out)/dt:.0f} files/s, "
           f"{frames/dt/1e6:.2f} Mframes/s end to end (decode + MFCC/RMS + pYIN), host cpus {os.cpu_count()}")
-    print("  phases (s):", {k: round(v, 4) for k, v in parallel.LAST_TIMING.items()})
+    print("  phases (s):", {k: round(v, 4) for k, v in parallel.LAST_TIMING.items() if k != "timeline"})
+    if os.environ.get("AFX_E2E_TIMELINE"):
+        for r in parallel.LAST_TIMING.get("timeline", []):
+            print("    sub-batch of %4d clips: begin %.1f ms, uploaded %.1f, f0 done %.1f, collected %.1f" % (r[1], r[2] * 1e3, r[3] * 1e3, r[4] * 1e3, r[5] * 1e3))
 # features_to_extract (README.md:141-146): the same directory without the pYIN pass
 for rep in range(2):
     t0 = time.perf_counter()
@@ -35,6 +38,9 @@ for rep in range(2):
     dt = time.perf_counter() - t0
     print(f"batch_process(features_to_extract=['mfcc', 'energy']): {len(out)} files in {dt*1e3:.0f} ms = {len(out)/dt:.0f} files/s "
           f"(decode + MFCC/RMS, no pYIN)")
-    print("  phases (s):", {k: round(v, 4) for k, v in parallel.LAST_TIMING.items()})
+    print("  phases (s):", {k: round(v, 4) for k, v in parallel.LAST_TIMING.items() if k != "timeline"})
+    if os.environ.get("AFX_E2E_TIMELINE"):
+        for r in parallel.LAST_TIMING.get("timeline", []):
+            print("    sub-batch of %4d clips: begin %.1f ms, uploaded %.1f, f0 done %.1f, collected %.1f" % (r[1], r[2] * 1e3, r[3] * 1e3, r[4] * 1e3, r[5] * 1e3))
 for f in os.listdir(d): os.remove(os.path.join(d, f))
 os.rmdir(d)
