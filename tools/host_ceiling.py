@@ -101,7 +101,7 @@ try:
         best = dt if best is None else min(best, dt)
         print(f"rep {rep}: {n} files x {dur:.0f} s over {ndev} fake devices in {dt * 1e3:.0f} ms = {n / dt:.0f} files/s "
               f"({n * int(22050 * dur) * 2 / dt / 1e9:.2f} GB/s of PCM16); phases (s): "
-              f"{ {k: round(v, 3) for k, v in parallel.LAST_TIMING.items()} }")
+              f"{ {k: round(v, 3) for k, v in parallel.LAST_TIMING.items() if k != 'timeline'} }")
     print(f"host ceiling: {n / best:.0f} files/s with {usable_cpus()} usable CPUs (os.cpu_count() = {os.cpu_count()}), "
           f"files on {'tmpfs' if base_dir else 'disk'}, touch = {touch}")
 finally:
