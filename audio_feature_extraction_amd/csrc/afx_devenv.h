@@ -16,7 +16,7 @@ struct DevEnv {
   bool no_dct16l = false;             // k_dct16<2|3> instead of k_dct16l (A/B)
   bool host_blocks = false;           // build the speculative block list on the host and upload it (A/B of k_build_blocks3)
   bool no_fused_tail = false;         // k_dct16* + k_stats instead of the fused per-clip DCT + statistics kernel (A/B)
-  int tail_mode = 0;                  // k_tail: 1 registers, 2 / 3 LDS-DMA ring of 4 waves x 4 tiles / 8 waves x 2 tiles (A/B)
+  int tail_mode = 0;                  // k_tail: 1 registers, 2 / 3 / 4 LDS-DMA ring of 4 waves x 4 tiles / 8 x 2 / 4 x 2 with two workgroups per CU (A/B)
   int f3_waves = 0;                   // 12 / 16: force the workgroup size of the wave-level frame kernels
   int chunk_clips = 32768;
   int64_t f0_chunk_frames = 1280 * 1024;

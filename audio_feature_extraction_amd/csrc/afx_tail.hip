@@ -385,12 +385,15 @@ hipError_t launch_tail(hipStream_t s, const ClipDesc* clips, const ClipInfo* inf
                        const float* logmel, const float* rms_rows, float* stats, ClipInfo* info_out, int n_clips, int spec,
                        int n_cu) {
   const int gh = tail_sym_groups(kp, tb);
-  // mode: 0 the shipped choice; 1 registers; 2 LDS-DMA ring, 4 waves x 4 tiles; 3 LDS-DMA ring, 8 waves x 2 tiles (A/B: AFX_TAIL_MODE)
+  // mode: 0 the shipped choice; 1 registers; LDS-DMA ring of 2: 4 waves x 4 tiles, 3: 8 waves x 2 tiles, 4: 4 waves x 2 tiles with two
+  // workgroups per CU (A/B: AFX_TAIL_MODE).  Shipped: 3, and 4 for up to 16 coefficients -- a clip is only 54 tiles, and with two
+  // clips per CU the reductions and the RMS pass at the end of one run beside the tiles of the other (cfg 2 step 0.686 -> 0.679 ms;
+  // with 40 coefficients the wider kernel loses 7 % that way, with 20 it makes no difference)
   int mode = dev_env().tail_mode;
   if (kp.n_mels != 128) mode = 1;                          // the ring's image is laid out for 512-byte rows
-  else if (mode == 0) mode = 3;
+  else if (mode == 0) mode = (gh == 0 && kp.n_mfcc <= 16) ? 4 : 3;
 #define AFX_TAIL_W(NG, SYM, TAB, W, R) launch_tail_t<NG, SYM, W, R>(s, clips, info, TAB, kp, logmel, rms_rows, stats, info_out, n_clips, spec, n_cu)
-#define AFX_TAIL(NG, SYM, TAB) (mode == 2 ? AFX_TAIL_W(NG, SYM, TAB, 4, 4) : mode == 3 ? AFX_TAIL_W(NG, SYM, TAB, 8, 2) : AFX_TAIL_W(NG, SYM, TAB, 4, 0))
+#define AFX_TAIL(NG, SYM, TAB) (mode == 2 ? AFX_TAIL_W(NG, SYM, TAB, 4, 4) : mode == 3 ? AFX_TAIL_W(NG, SYM, TAB, 8, 2) : mode == 4 ? AFX_TAIL_W(NG, SYM, TAB, 4, 2) : AFX_TAIL_W(NG, SYM, TAB, 4, 0))
   if (gh == 1) return AFX_TAIL(2, true, tb.dctS);
   if (gh == 2) return AFX_TAIL(4, true, tb.dctS);
   switch ((kp.n_mfcc + 15) / 16) {

@@ -229,7 +229,7 @@ print("ok")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"AFX_TAIL_MODE": "1"}, {"AFX_TAIL_MODE": "2"}, {"AFX_TAIL_MODE": "3"}, {"AFX_NO_FUSED_TAIL": "1"},
+@pytest.mark.parametrize("env", [{"AFX_TAIL_MODE": "1"}, {"AFX_TAIL_MODE": "2"}, {"AFX_TAIL_MODE": "3"}, {"AFX_TAIL_MODE": "4"}, {"AFX_NO_FUSED_TAIL": "1"},
                                  {"AFX_HOST_BLOCKS": "1"}, {"AFX_F3_GENERIC_MEL": "1"}, {"AFX_NO_SPEC": "1"}, {"AFX_F3_WAVES": "12"}])
 def test_every_ab_switch_is_parity_green(env):
     """The developer switches (afx_devenv.h) select other kernels / other routes for the same results: the register-path and
