@@ -27,6 +27,13 @@
 
 namespace afx {
 
+// The timing-only ablation switches and per-phase cycle stamps of AFX_F0_DEBUG exist in libafx_dbg.so only (make dbg:
+// -DAFX_F0_DEBUG_BUILD=1); the product library ignores the variable and carries neither the code nor its registers.
+#ifndef AFX_F0_DEBUG_BUILD
+#define AFX_F0_DEBUG_BUILD 0
+#endif
+constexpr bool kF0Dbg = AFX_F0_DEBUG_BUILD != 0;
+
 #define F0_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 __device__ __forceinline__ double shfl_d(double v, int src) {
@@ -305,7 +312,8 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
 
   const bool shared_chunks = W == 2 * hop;
   // AFX_F0_DEBUG & 32: cycles per phase of workgroup (0, 0), printed per wave (developer aid)
-  const bool stamping = (fp.debug & 32) != 0;
+  const int ydbg = kF0Dbg ? fp.debug : 0;
+  const bool stamping = kF0Dbg && (ydbg & 32) != 0;
   unsigned long long ph[8] = {}, ph_t = 0;
   auto stamp = [&](int i) {
     if (stamping) {
@@ -369,11 +377,11 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
     if (shared_chunks) {
       double cur[RR];
       if (fi == 0) chunk(F, hop, carry);
-      chunk(F + hop, (fp.debug & 4) ? 8 : hop, cur);
+      chunk(F + hop, (ydbg & 4) ? 8 : hop, cur);
 #pragma unroll
       for (int r = 0; r < RR; ++r) { acc[r] = carry[r] + cur[r]; carry[r] = cur[r]; }
     } else {
-      chunk(F, (fp.debug & 4) ? 8 : W, acc);
+      chunk(F, (ydbg & 4) ? 8 : W, acc);
     }
     stamp(0);
     // ---- difference function d = (e[0] + e[tau]) [float32] - 2 acf [float64]
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
       // one after the other as before (the sums are bit-identical to re-ranking at every threshold; librosa takes
       // them as a BLAS dot, whose order is not pinned, and a strongly voiced frame's total decides between an
       // unvoiced observation of 0 and of 2e-19 -- see DESIGN.md 7 -- so the order is not touched).
-      const int kmax = (fp.debug & 8) ? 4 : kF0Thresholds;
+      const int kmax = (ydbg & 8) ? 4 : kF0Thresholds;
       int kin[CSM];
 #pragma unroll
       for (int c = 0; c < CSM; ++c) {
@@ -1308,9 +1316,12 @@ hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInf
                        cand_cnt, cand_bin, cand_lp, cand_lu, vrows, vbest);                                          \
   } while (0)
   const bool ref_shape = fp.n_bins == 601 && fp.band == 25;       // fmin / fmax of the reference at hop / sr = 256 / 22050, 512 / 44100
+#if AFX_F0_DEBUG_BUILD
   if (fp.debug & 16) AFX_VIT_LAUNCH(2, 0, 0);
   else if (fp.debug) { if (ref_shape) AFX_VIT_LAUNCH(1, 601, 25); else AFX_VIT_LAUNCH(1, 0, 0); }
-  else if (ref_shape) AFX_VIT_LAUNCH(0, 601, 25);
+  else
+#endif
+  if (ref_shape) AFX_VIT_LAUNCH(0, 601, 25);
   else AFX_VIT_LAUNCH(0, 0, 0);
 #undef AFX_VIT_LAUNCH
   if ((e = hipGetLastError()) != hipSuccess) return e;
