@@ -232,13 +232,13 @@ __global__ __launch_bounds__(64 * kEnergyWaves) void k_f0_energy(const float* __
 // ---------------------------------------------------------------------------------------------
 
 struct YinLds { size_t span, per_wave, tables, total; };
-__host__ __device__ inline YinLds yin_lds(const F0Params& fp, int fpb, bool yf) {
+__host__ __device__ inline YinLds yin_lds_i(int hop_, int n_fft_, int n_tau_pad_, int slots_, int cap_, int fpb, bool yf) {
   YinLds L;
-  L.span = (size_t)(fpb - 1) * fp.hop + fp.n_fft + 64;
+  L.span = (size_t)(fpb - 1) * hop_ + n_fft_ + 64;
   // per wave (doubles): D[n_tau_pad] | X[slots*64 + 2] | CP[cap] | CB[cap] (ints, cap/2 doubles)
-  L.per_wave = (size_t)fp.n_tau_pad + (size_t)fp.slots * 64 + 2 + fp.cap + (fp.cap + 1) / 2;
+  L.per_wave = (size_t)n_tau_pad_ + (size_t)slots_ * 64 + 2 + cap_ + (cap_ + 1) / 2;
   // shared tables: thr[101] | beta[100] | cumbeta[101] | bfact[cap+1] | bexp[cap+1]
-  L.tables = 101 + 100 + 101 + 2 * ((size_t)fp.cap + 1);
+  L.tables = 101 + 100 + 101 + 2 * ((size_t)cap_ + 1);
   // the staged signal is kept as the float32 it is (converted on read: half the bytes of the autocorrelation's LDS reads and
   // 20 KB less per workgroup); span is rounded up to an even count so that the double arrays behind it stay 8-byte aligned
   // (yf: the instantiations with at most 6 lags per lane; the lag-heavy ones re-read the signal 11..16 times per step and keep it
@@ -246,6 +246,9 @@ __host__ __device__ inline YinLds yin_lds(const F0Params& fp, int fpb, bool yf) 
   L.span = (L.span + 1) & ~(size_t)1;
   L.total = L.span * (yf ? sizeof(float) : sizeof(double)) + (4 * L.per_wave + L.tables) * sizeof(double);
   return L;
+}
+__host__ __device__ inline YinLds yin_lds(const F0Params& fp, int fpb, bool yf) {
+  return yin_lds_i(fp.hop, fp.n_fft, fp.n_tau_pad, fp.slots, fp.cap, fpb, yf);
 }
 // frames one workgroup owns: 16, or 8 where that (and only that) lets a third workgroup onto the CU -- the kernel is bound by
 // how often a wave gets to issue, and the lag-heavy instantiations (more than 6 lags per lane) cannot use a third wave anyway
@@ -260,7 +263,9 @@ size_t f0_yin_lds_bytes(const F0Params& fp) {
 }
 
 // RR >= lags per lane (fp.R), SS >= trough slots per lane (fp.slots): per-lane arrays are sized by them
-template <int RR, int SS, int FPB>
+// REF: the reference's shape (22050 Hz, frame_length 1024, C2..C7) compiled in -- periods 10..338, 339 lags in rows of 384,
+// 329 kept, 168 candidates at most, 601 pitch bins: the kernel is short of scalar registers, and offsets become immediates.
+template <int RR, int SS, int FPB, bool REF>
 __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* __restrict__ ysig,
                                                 const ClipDesc* __restrict__ clips,
                                                 const ClipInfo* __restrict__ info,
@@ -282,26 +287,29 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr bool YF = RR <= 6;
   typedef typename std::conditional<YF, float, double>::type ysig_t;
-  const YinLds L = yin_lds(fp, FPB, YF);
+  const int hop = REF ? 256 : fp.hop, W = REF ? 512 : fp.W, R = REF ? 6 : fp.R, slots = REF ? 6 : fp.slots, n_lag = REF ? 329 : fp.n_lag;
+  const int n_fft = REF ? 1024 : fp.n_fft, n_tau = REF ? 339 : fp.n_tau, n_tau_pad = REF ? 384 : fp.n_tau_pad;
+  const int min_period = REF ? 10 : fp.min_period, max_period = REF ? 338 : fp.max_period, cap = REF ? 168 : fp.cap;
+  const int n_bins = REF ? 601 : fp.n_bins;
+  const YinLds L = yin_lds_i(hop, n_fft, n_tau_pad, slots, cap, FPB, YF);
   ysig_t* Y = reinterpret_cast<ysig_t*>(smy);
   double* const smd = smy + (YF ? L.span / 2 : L.span);       // the double arrays behind the staged signal
   double* D = smd + (size_t)wave * L.per_wave;
-  double* X = D + fp.n_tau_pad;
-  double* CP = X + fp.slots * 64 + 2;
-  int* CB = reinterpret_cast<int*>(CP + fp.cap);
-  const int hop = fp.hop, W = fp.W, R = fp.R, slots = fp.slots, n_lag = fp.n_lag;
+  double* X = D + n_tau_pad;
+  double* CP = X + slots * 64 + 2;
+  int* CB = reinterpret_cast<int*>(CP + cap);
   // the probability tables are read inside the threshold loop with data-dependent indices: keep them in LDS
   double* Tthr = smd + 4 * L.per_wave;
   double* Tbeta = Tthr + 101;
   double* Tcum = Tbeta + 100;
   double* Tfact = Tcum + 101;
-  double* Texp = Tfact + fp.cap + 1;
+  double* Texp = Tfact + cap + 1;
   for (int i = tid; i < 101; i += 256) { Tthr[i] = tb.thr[i]; Tcum[i] = tb.cumbeta[i]; }
   for (int i = tid; i < 100; i += 256) Tbeta[i] = tb.beta[i];
-  for (int i = tid; i <= fp.cap; i += 256) { Tfact[i] = tb.bfact[i]; Texp[i] = tb.bexp[i]; }
+  for (int i = tid; i <= cap; i += 256) { Tfact[i] = tb.bfact[i]; Texp[i] = tb.bexp[i]; }
 
   {
-    const int64_t g0 = (int64_t)t0 * hop - fp.n_fft / 2;
+    const int64_t g0 = (int64_t)t0 * hop - n_fft / 2;
     const float* y = ysig + cd.off;
     for (int i = tid; i < (int)L.span; i += 256) {
       const int64_t g = g0 + i;
@@ -385,12 +393,12 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
     }
     stamp(0);
     // ---- difference function d = (e[0] + e[tau]) [float32] - 2 acf [float64]
-    const float* Erow = energy + slot * (int64_t)fp.n_tau_pad;
+    const float* Erow = energy + slot * (int64_t)n_tau_pad;
     const float e0 = Erow[0];
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
       const int tau = lane + 64 * r;
-      if (r < R && tau < fp.n_tau) {
+      if (r < R && tau < n_tau) {
         double a = acc[r];
         if (fabs(a) < 1e-6) a = 0.0;
         const float s32 = e0 + Erow[tau];
@@ -400,19 +408,19 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
     F0_WAVE_SYNC();
     // ---- cumulative mean over tau = 1 .. max_period, kept for tau >= min_period
     {
-      const int C = (fp.max_period + 63) / 64;
+      const int C = (max_period + 63) / 64;
       const int lo = 1 + lane * C;
       double s = 0.0;
-      for (int k = 0; k < C; ++k) { const int tau = lo + k; if (tau <= fp.max_period) s += D[tau]; }
+      for (int k = 0; k < C; ++k) { const int tau = lo + k; if (tau <= max_period) s += D[tau]; }
       double incl = s;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const double v = shfl_up_d(incl, o); if (lane >= o) incl += v; }
       double run = incl - s;
       for (int k = 0; k < C; ++k) {
         const int tau = lo + k;
-        if (tau <= fp.max_period) {
+        if (tau <= max_period) {
           run += D[tau];
-          if (tau >= fp.min_period) X[tau - fp.min_period] = D[tau] / (run / (double)tau + fp.tiny);
+          if (tau >= min_period) X[tau - min_period] = D[tau] / (run / (double)tau + fp.tiny);
         }
       }
     }
@@ -562,10 +570,10 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
               const double b = (xp - xm) / 2.0;
               shift = fabs(b) >= fabs(a) ? 0.0 : -b / a;
             }
-            const double period = (double)(fp.min_period + p) + shift;
+            const double period = (double)(min_period + p) + shift;
             const double f0 = fp.sr / period;
             double bf = rint(fp.bins_per_octave * log2(f0 / fp.fmin));
-            bf = bf < 0.0 ? 0.0 : (bf > (double)fp.n_bins ? (double)fp.n_bins : bf);
+            bf = bf < 0.0 ? 0.0 : (bf > (double)n_bins ? (double)n_bins : bf);
             const int j = cnt + lanes_below(m);
             CB[j] = (int)bf;
             CP[j] = pr[c];
@@ -585,9 +593,9 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
           const int b = CB[j];
           const bool keep = (j == cnt - 1) || CB[j + 1] != b;
           const double pj = CP[j];
-          cand_bin[slot * fp.cap + j] = (int16_t)(keep ? b : -1);
-          cand_prob[slot * fp.cap + j] = pj;
-          if (keep && b >= 0 && b < fp.n_bins) val[m] = pj;
+          cand_bin[slot * cap + j] = (int16_t)(keep ? b : -1);
+          cand_prob[slot * cap + j] = pj;
+          if (keep && b >= 0 && b < n_bins) val[m] = pj;
         }
       }
       // voiced_prob = np.sum(observation[:n_bins], axis=0): numpy adds the rows one after another, i.e. the kept
@@ -1263,13 +1271,18 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
   const int fpb = f0_yin_frames_per_block(fp);
   dim3 grid((max_tmax + fpb - 1) / fpb, n_clips);
   const int need = fp.R > fp.slots ? fp.R : fp.slots;
-#define AFX_YIN_LAUNCH_F(N, F)                                                                                  \
+#define AFX_YIN_LAUNCH_FR(N, F, REF)                                                                            \
   do {                                                                                                         \
-    hipError_t e2 = allow_lds(k_f0_yin<N, N, F>, lds);                                                         \
+    hipError_t e2 = allow_lds(k_f0_yin<N, N, F, REF>, lds);                                                    \
     if (e2 != hipSuccess) return e2;                                                                           \
-    hipLaunchKernelGGL((k_f0_yin<N, N, F>), grid, dim3(256), lds, s, ysig, clips, info, energy, tb, fp, cand_cnt, \
+    hipLaunchKernelGGL((k_f0_yin<N, N, F, REF>), grid, dim3(256), lds, s, ysig, clips, info, energy, tb, fp, cand_cnt, \
                        cand_vp, cand_bin, cand_prob);                                                          \
   } while (0)
+#define AFX_YIN_LAUNCH_F(N, F) AFX_YIN_LAUNCH_FR(N, F, false)
+  const bool ref_shape = fp.hop == 256 && fp.W == 512 && fp.n_fft == 1024 && fp.R == 6 && fp.slots == 6 && fp.n_lag == 329 &&
+                         fp.n_tau == 339 && fp.n_tau_pad == 384 && fp.min_period == 10 && fp.max_period == 338 && fp.cap == 168 &&
+                         fp.n_bins == 601 && fpb == 8;
+  if (ref_shape) { AFX_YIN_LAUNCH_FR(6, 8, true); return hipGetLastError(); }
 #define AFX_YIN_LAUNCH(N) do { if (fpb == 8) AFX_YIN_LAUNCH_F(N, 8); else AFX_YIN_LAUNCH_F(N, 16); } while (0)
   if (need <= 4) AFX_YIN_LAUNCH(4);
   else if (need <= 6) AFX_YIN_LAUNCH(6);
@@ -1278,6 +1291,7 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
   else AFX_YIN_LAUNCH_F(16, 16);
 #undef AFX_YIN_LAUNCH
 #undef AFX_YIN_LAUNCH_F
+#undef AFX_YIN_LAUNCH_FR
   return hipGetLastError();
 }
 
