@@ -228,6 +228,119 @@ __global__ __launch_bounds__(64 * kEnergyWaves) void k_f0_energy(const float* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_f0_energy2: the same rows without the tau-history.  e[tau] is needed W steps after the chain has passed it, and
+// keeping it cost 1.35 KB of LDS per frame -- 157 KB per workgroup of 64 frames: one workgroup, one wave per SIMD, on a
+// chain whose every step waits for the one before.  Instead the lane runs the chain a second time, W steps behind:
+// a[tau] = e[tau] is re-formed from the same samples in the same order (bit for bit the same float32 sums) while the
+// first chain is at e[W + tau], 40 % more additions on lanes that were waiting anyway, and two independent chains per
+// lane where they overlap.  LDS then holds the samples only (1 KB per frame), so LPW lanes per wave (LPW 8: 32 frames,
+// 37 KB) leave room for four workgroups per CU, four waves per SIMD.  The differences leave through a wave-local
+// [frame][32 lags] tile: every 32 lags the wave's 64 lanes write its frames' pieces of the rows, 128 bytes each.
+// Needs W % hop == 0 (the pads of the two index streams then coincide); anything else takes k_f0_energy.
+// ---------------------------------------------------------------------------------------------
+constexpr int kE2Tile = 32;
+__host__ __device__ inline size_t f0_energy2_span(const F0Params& fp, int lpw) {
+  return (size_t)(kEnergyWaves * lpw - 1) * fp.hop + fp.W + fp.n_tau;
+}
+size_t f0_energy2_lds_bytes(const F0Params& fp, int lpw) {
+  const size_t span = f0_energy2_span(fp, lpw);
+  return (span + span / fp.hop + 8 + (size_t)kEnergyWaves * lpw * (kE2Tile + 1)) * 4;
+}
+
+template <int LPW>
+__global__ __launch_bounds__(64 * kEnergyWaves) void k_f0_energy2(const float* __restrict__ ysig,
+                                                                  const ClipDesc* __restrict__ clips,
+                                                                  const ClipInfo* __restrict__ info,
+                                                                  float* __restrict__ energy, F0Params fp) {
+  extern __shared__ float sme[];
+  const int clip = blockIdx.y;
+  const ClipInfo ci = info[clip];
+  if (ci.status == AFX_CLIP_NONFINITE) return;
+  constexpr int E = kEnergyWaves * LPW;
+  const int T = ci.T, hop = fp.hop, W = fp.W, n_tau = fp.n_tau;
+  const int t0 = blockIdx.x * E;
+  if (t0 >= T) return;
+  const ClipDesc cd = clips[clip];
+  const int64_t np = ci.end - ci.start;
+  constexpr int NT = 64 * kEnergyWaves;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int span = (int)f0_energy2_span(fp, LPW);
+  float* S = sme;
+  float* OB = sme + (span + span / hop + 8) + wave * LPW * (kE2Tile + 1);     // this wave's [frame][lag] tile
+  const int64_t g0 = (int64_t)t0 * hop - fp.n_fft / 2;
+  const float* y = ysig + cd.off;
+  for (int i = tid; i < span; i += NT) {
+    const int64_t g = g0 + i;
+    S[i + i / hop] = (g >= 0 && g < np) ? y[g] : 0.f;
+  }
+  __syncthreads();
+  const int fr = wave * LPW + lane;                                 // this lane's frame of the block
+  const bool chain = lane < LPW && t0 + fr < T;
+  // padded index of sample fr * hop + n is fr * (hop + 1) + n + n / hop; a run stays inside one hop-sized piece
+  const float* base = S + (chain ? fr : 0) * (hop + 1);
+  float e = 0.f, a = 0.f;
+  if (chain) {                                                      // e[0 .. W - 1]: nothing leaves
+    for (int r0 = 0; r0 < W; r0 += hop) {
+      const float* sp = base + r0 + r0 / hop;
+      int n = 0;
+      for (; n + 8 <= hop; n += 8) {
+        float yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) yv[u] = sp[n + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e = sq_acc(e, yv[u]);
+      }
+      for (; n < hop; ++n) e = sq_acc(e, sp[n]);
+    }
+  }
+  const int wq = W / hop;                                           // pads between sample tau and sample W + tau
+  for (int tb = 0; tb < n_tau; tb += kE2Tile) {
+    const int te = tb + kE2Tile < n_tau ? tb + kE2Tile : n_tau;
+    if (chain) {
+      int tau = tb;
+      while (tau < te) {                                            // runs between the pads (a tile may straddle one)
+        const int stop = (tau / hop + 1) * hop;
+        const int re = stop < te ? stop : te;
+        const float* pa = base + tau / hop;                        // + tau
+        const float* pe = pa + W + wq;                              // sample W + tau
+        float* ob = OB + lane * (kE2Tile + 1) - tb;
+        int n = tau;
+        for (; n + 8 <= re; n += 8) {
+          float ya[8], ye[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { ya[u] = pa[n + u]; ye[u] = pe[n + u]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            a = sq_acc(a, ya[u]);
+            e = sq_acc(e, ye[u]);
+            float d = e - a;
+            if (fabsf(d) < 1e-6f) d = 0.f;
+            ob[n + u] = d;
+          }
+        }
+        for (; n < re; ++n) {
+          a = sq_acc(a, pa[n]);
+          e = sq_acc(e, pe[n]);
+          float d = e - a;
+          if (fabsf(d) < 1e-6f) d = 0.f;
+          ob[n] = d;
+        }
+        tau = re;
+      }
+    }
+    F0_WAVE_SYNC();
+    // the wave's LPW rows of this tile: lanes (row, lag) = (i / 32, i % 32), 128 bytes of a row per 32 lanes
+    for (int i = lane; i < LPW * kE2Tile; i += 64) {
+      const int r = i / kE2Tile, c = i % kE2Tile;
+      const int f = wave * LPW + r;
+      if (t0 + f < T && tb + c < te)
+        energy[(cd.frame_base + t0 + f) * (int64_t)fp.n_tau_pad + tb + c] = OB[r * (kE2Tile + 1) + c];
+    }
+    F0_WAVE_SYNC();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_f0_yin
 // ---------------------------------------------------------------------------------------------
 
@@ -1255,9 +1368,20 @@ static hipError_t allow_lds(K kernel, size_t bytes) {
 
 hipError_t launch_f0_energy(hipStream_t s, const float* ysig, const ClipDesc* clips, const ClipInfo* info,
                             float* energy, int n_clips, int max_tmax, const F0Params& fp) {
+  hipError_t e;
+  if (fp.W % fp.hop == 0 && fp.n_tau <= fp.W) {
+    // lanes per wave: as many as keep the workgroup's samples within a quarter of the CU's LDS (four workgroups per CU)
+    constexpr int lpw = 8;
+    const size_t lds2 = f0_energy2_lds_bytes(fp, lpw);
+    if (lds2 <= 40 * 1024) {
+      if ((e = allow_lds(k_f0_energy2<lpw>, lds2)) != hipSuccess) return e;
+      dim3 grid2((max_tmax + kEnergyWaves * lpw - 1) / (kEnergyWaves * lpw), n_clips);
+      hipLaunchKernelGGL(k_f0_energy2<lpw>, grid2, dim3(64 * kEnergyWaves), lds2, s, ysig, clips, info, energy, fp);
+      return hipGetLastError();
+    }
+  }
   const size_t lds = f0_energy_lds_bytes(fp);
-  hipError_t e = allow_lds(k_f0_energy, lds);
-  if (e != hipSuccess) return e;
+  if ((e = allow_lds(k_f0_energy, lds)) != hipSuccess) return e;
   dim3 grid((max_tmax + fp.epb - 1) / fp.epb, n_clips);
   hipLaunchKernelGGL(k_f0_energy, grid, dim3(64 * kEnergyWaves), lds, s, ysig, clips, info, energy, fp);
   return hipGetLastError();
