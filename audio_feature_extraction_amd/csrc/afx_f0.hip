@@ -1370,15 +1370,20 @@ hipError_t launch_f0_energy(hipStream_t s, const float* ysig, const ClipDesc* cl
                             float* energy, int n_clips, int max_tmax, const F0Params& fp) {
   hipError_t e;
   if (fp.W % fp.hop == 0 && fp.n_tau <= fp.W) {
-    // lanes per wave: as many as keep the workgroup's samples within a quarter of the CU's LDS (four workgroups per CU)
-    constexpr int lpw = 8;
-    const size_t lds2 = f0_energy2_lds_bytes(fp, lpw);
-    if (lds2 <= 40 * 1024) {
-      if ((e = allow_lds(k_f0_energy2<lpw>, lds2)) != hipSuccess) return e;
-      dim3 grid2((max_tmax + kEnergyWaves * lpw - 1) / (kEnergyWaves * lpw), n_clips);
-      hipLaunchKernelGGL(k_f0_energy2<lpw>, grid2, dim3(64 * kEnergyWaves), lds2, s, ysig, clips, info, energy, fp);
-      return hipGetLastError();
-    }
+    // lanes per wave: 8, or 4 for the long hops, if that keeps the workgroup's samples within a quarter of the CU's LDS
+    // (four workgroups per CU)
+#define AFX_E2_LAUNCH(LPW)                                                                                               \
+    do {                                                                                                                 \
+      const size_t lds2 = f0_energy2_lds_bytes(fp, LPW);                                                                 \
+      if (lds2 <= 40 * 1024) {                                                                                           \
+        dim3 grid2((max_tmax + kEnergyWaves * LPW - 1) / (kEnergyWaves * LPW), n_clips);                                 \
+        hipLaunchKernelGGL(k_f0_energy2<LPW>, grid2, dim3(64 * kEnergyWaves), lds2, s, ysig, clips, info, energy, fp);   \
+        return hipGetLastError();                                                                                        \
+      }                                                                                                                  \
+    } while (0)
+    AFX_E2_LAUNCH(8);
+    AFX_E2_LAUNCH(4);
+#undef AFX_E2_LAUNCH
   }
   const size_t lds = f0_energy_lds_bytes(fp);
   if ((e = allow_lds(k_f0_energy, lds)) != hipSuccess) return e;
