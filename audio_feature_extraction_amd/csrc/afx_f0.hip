@@ -776,16 +776,21 @@ size_t f0_viterbi_lds_bytes(const F0Params& fp) { return vit_lds(fp.n_bins, fp.b
 // k_f0_logs: the log observation values the Viterbi pass scatters -- log(p + tiny) per candidate and the unvoiced
 // bins' common log((1 - voiced_prob) / n_bins + tiny) -- one wave per frame slot.  Kept out of the Viterbi step
 // loop, where a wave's instruction count is the critical path.
+constexpr int kLogsPerWave = 8;
 __global__ __launch_bounds__(256) void k_f0_logs(const int32_t* __restrict__ cand_cnt, const double* __restrict__ cand_vp,
                                                  const double* __restrict__ cand_prob, double* __restrict__ cand_lp,
                                                  double* __restrict__ cand_lu, int64_t frames, F0Params fp) {
-  const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // a wave takes kLogsPerWave consecutive frame slots (one each made 864 000 waves of a few instructions for 1000 clips)
   const int lane = threadIdx.x & 63;
-  if (f >= frames) return;
-  int cnt = cand_cnt[f];                                 // slots between clips hold nothing: any value is harmless
-  cnt = cnt < 0 ? 0 : (cnt > fp.cap ? fp.cap : cnt);
-  for (int i = lane; i < cnt; i += 64) cand_lp[f * fp.cap + i] = log(cand_prob[f * fp.cap + i] + fp.tiny);
-  if (lane == 0) cand_lu[f] = log((1.0 - cand_vp[f]) / (double)fp.n_bins + fp.tiny);
+  const int64_t f0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kLogsPerWave;
+  for (int u = 0; u < kLogsPerWave; ++u) {
+    const int64_t f = f0 + u;
+    if (f >= frames) return;
+    int cnt = cand_cnt[f];                               // slots between clips hold nothing: any value is harmless
+    cnt = cnt < 0 ? 0 : (cnt > fp.cap ? fp.cap : cnt);
+    for (int i = lane; i < cnt; i += 64) cand_lp[f * fp.cap + i] = log(cand_prob[f * fp.cap + i] + fp.tiny);
+    if (lane == 0) cand_lu[f] = log((1.0 - cand_vp[f]) / (double)fp.n_bins + fp.tiny);
+  }
 }
 
 // MODE 0: production; 1: the timing-only ablation bits of AFX_F0_DEBUG honoured; 2: per-phase cycle stamps as well.
@@ -1448,7 +1453,7 @@ hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInf
                              int64_t frames, double* vrows, VitBest* vbest,
                              uint16_t* states, double* out_stats, double* out_f0, const int64_t* f0_offsets,
                              int n_clips) {
-  hipLaunchKernelGGL(k_f0_logs, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, s, cand_cnt, cand_vp, cand_prob, cand_lp,
+  hipLaunchKernelGGL(k_f0_logs, dim3((unsigned)((frames + 4 * kLogsPerWave - 1) / (4 * kLogsPerWave))), dim3(256), 0, s, cand_cnt, cand_vp, cand_prob, cand_lp,
                      cand_lu, frames, fp);
   const size_t lds = f0_viterbi_lds_bytes(fp);
   hipError_t e;
