@@ -76,11 +76,20 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {       // s
 template <int CTRL> __device__ __forceinline__ double dpp_dd(double v) {
   return __hiloint2double(F0_DPP_I(__double2hiint(v), CTRL), F0_DPP_I(__double2loint(v), CTRL));
 }
+// max of two doubles that are never NaN, as the one instruction it is: fmax() makes the compiler quiet a possible signalling
+// NaN in every operand whose origin it cannot see (a v_max_f64 x, x, x in front of the real one -- for values read from LDS,
+// moved by DPP, or merged from two branches)
+__device__ __forceinline__ double max_nn(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ double wave_max_dpp(double v) {         // uniform result
-  v = fmax(v, dpp_dd<0xB1>(v));      // quad_perm [1,0,3,2]
-  v = fmax(v, dpp_dd<0x4E>(v));      // quad_perm [2,3,0,1]
-  v = fmax(v, dpp_dd<0x141>(v));     // row_half_mirror
-  v = fmax(v, dpp_dd<0x140>(v));     // row_mirror
+  v = max_nn(v, dpp_dd<0xB1>(v));    // quad_perm [1,0,3,2]      (callers: Viterbi values, -inf or finite)
+  v = max_nn(v, dpp_dd<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = max_nn(v, dpp_dd<0x141>(v));   // row_half_mirror
+  v = max_nn(v, dpp_dd<0x140>(v));   // row_mirror
   const int lo = __double2loint(v), hi = __double2hiint(v);
   auto rl = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l)); };
   return fmax(fmax(rl(0), rl(16)), fmax(rl(32), rl(48)));
@@ -99,15 +108,6 @@ __device__ __forceinline__ void lds_fmax(double* p, double v) {      // *p = max
 #pragma clang diagnostic ignored "-Wold-style-cast"
   __hip_atomic_fetch_max((__attribute__((address_space(3))) double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma clang diagnostic pop
-}
-
-// max of two doubles that are never NaN, as the one instruction it is: fmax() makes the compiler quiet a possible signalling
-// NaN in every operand whose origin it cannot see (a v_max_f64 x, x, x in front of the real one -- for values read from LDS,
-// moved by DPP, or merged from two branches)
-__device__ __forceinline__ double max_nn(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
 }
 
 typedef const double __attribute__((address_space(4))) cdouble_k;   // constant address space: uniform reads become s_load
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   // the same over the first 16 lanes only (the per-wave partials): one DPP row, one readlane
   auto row0_best = [&](double& bv, int& bi) {
     double v = bv;
-    v = fmax(v, dpp_dd<0xB1>(v)); v = fmax(v, dpp_dd<0x4E>(v)); v = fmax(v, dpp_dd<0x141>(v)); v = fmax(v, dpp_dd<0x140>(v));
+    v = max_nn(v, dpp_dd<0xB1>(v)); v = max_nn(v, dpp_dd<0x4E>(v)); v = max_nn(v, dpp_dd<0x141>(v)); v = max_nn(v, dpp_dd<0x140>(v));
     const double m = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
     const unsigned long long at = __ballot(bv == m) & 0xffffull;
     if (__popcll(at) == 1) bi = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(at));
