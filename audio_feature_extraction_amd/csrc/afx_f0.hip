@@ -345,7 +345,10 @@ __global__ __launch_bounds__(64 * kEnergyWaves) void k_f0_energy2(const float* _
 // ---------------------------------------------------------------------------------------------
 
 struct YinLds { size_t span, per_wave, tables, total; };
-__host__ __device__ inline YinLds yin_lds_i(int hop_, int n_fft_, int n_tau_pad_, int slots_, int cap_, int fpb, bool yf) {
+// compact (the REF instantiation): the trough / candidate arrays CP, CB live in the D row behind its 64 event flags -- D is
+// idle once the normalised difference is formed -- and the two tables that are only read with uniform indices (beta,
+// cumbeta) come through the scalar cache: 39.7 KB per workgroup, a fourth workgroup per CU
+__host__ __device__ inline YinLds yin_lds_i(int hop_, int n_fft_, int n_tau_pad_, int slots_, int cap_, int fpb, bool yf, bool compact = false) {
   YinLds L;
   L.span = (size_t)(fpb - 1) * hop_ + n_fft_ + 64;
   // per wave (doubles): D[n_tau_pad] | X[slots*64 + 2] | CP[cap] | CB[cap] (ints, cap/2 doubles)
@@ -357,6 +360,10 @@ __host__ __device__ inline YinLds yin_lds_i(int hop_, int n_fft_, int n_tau_pad_
   // (yf: the instantiations with at most 6 lags per lane; the lag-heavy ones re-read the signal 11..16 times per step and keep it
   // as float64 -- a conversion per read costs them more than the bytes)
   L.span = (L.span + 1) & ~(size_t)1;
+  if (compact) {
+    L.per_wave = (size_t)n_tau_pad_ + (size_t)slots_ * 64 + 2;
+    L.tables = 101 + 2 * ((size_t)cap_ + 1);
+  }
   L.total = L.span * (yf ? sizeof(float) : sizeof(double)) + (4 * L.per_wave + L.tables) * sizeof(double);
   return L;
 }
@@ -379,7 +386,7 @@ size_t f0_yin_lds_bytes(const F0Params& fp) {
 // REF: the reference's shape (22050 Hz, frame_length 1024, C2..C7) compiled in -- periods 10..338, 339 lags in rows of 384,
 // 329 kept, 168 candidates at most, 601 pitch bins: the kernel is short of scalar registers, and offsets become immediates.
 template <int RR, int SS, int FPB, bool REF>
-__global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* __restrict__ ysig,
+__global__ __launch_bounds__(256, (REF ? 4 : RR <= 6 ? 3 : 1)) void k_f0_yin(const float* __restrict__ ysig,
                                                 const ClipDesc* __restrict__ clips,
                                                 const ClipInfo* __restrict__ info,
                                                 const float* __restrict__ energy,
@@ -404,22 +411,30 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
   const int n_fft = REF ? 1024 : fp.n_fft, n_tau = REF ? 339 : fp.n_tau, n_tau_pad = REF ? 384 : fp.n_tau_pad;
   const int min_period = REF ? 10 : fp.min_period, max_period = REF ? 338 : fp.max_period, cap = REF ? 168 : fp.cap;
   const int n_bins = REF ? 601 : fp.n_bins;
-  const YinLds L = yin_lds_i(hop, n_fft, n_tau_pad, slots, cap, FPB, YF);
+  const YinLds L = yin_lds_i(hop, n_fft, n_tau_pad, slots, cap, FPB, YF, REF);
+  static_assert(!REF || 64 + 168 + 84 <= 384, "CP / CB behind the event flags of the D row");
   ysig_t* Y = reinterpret_cast<ysig_t*>(smy);
   double* const smd = smy + (YF ? L.span / 2 : L.span);       // the double arrays behind the staged signal
   double* D = smd + (size_t)wave * L.per_wave;
   double* X = D + n_tau_pad;
-  double* CP = X + slots * 64 + 2;
+  double* CP = REF ? D + 64 : X + slots * 64 + 2;
   int* CB = reinterpret_cast<int*>(CP + cap);
   // the probability tables are read inside the threshold loop with data-dependent indices: keep them in LDS
   double* Tthr = smd + 4 * L.per_wave;
-  double* Tbeta = Tthr + 101;
-  double* Tcum = Tbeta + 100;
-  double* Tfact = Tcum + 101;
+  double* Tfact = Tthr + 101;
   double* Texp = Tfact + cap + 1;
-  for (int i = tid; i < 101; i += 256) { Tthr[i] = tb.thr[i]; Tcum[i] = tb.cumbeta[i]; }
-  for (int i = tid; i < 100; i += 256) Tbeta[i] = tb.beta[i];
+  double* TbetaL = Texp + cap + 1;                              // (not REF) the two uniformly indexed tables
+  double* TcumL = TbetaL + 100;
+  for (int i = tid; i < 101; i += 256) Tthr[i] = tb.thr[i];
   for (int i = tid; i <= cap; i += 256) { Tfact[i] = tb.bfact[i]; Texp[i] = tb.bexp[i]; }
+  if constexpr (!REF) {
+    for (int i = tid; i < 101; i += 256) TcumL[i] = tb.cumbeta[i];
+    for (int i = tid; i < 100; i += 256) TbetaL[i] = tb.beta[i];
+  }
+  cdouble_k* const beta_k = as_constant(tb.beta);
+  cdouble_k* const cum_k = as_constant(tb.cumbeta);
+  auto Tbeta_at = [&](int i) -> double { if constexpr (REF) return beta_k[i]; else return TbetaL[i]; };
+  auto Tcum_at = [&](int i) -> double { if constexpr (REF) return cum_k[i]; else return TcumL[i]; };
 
   {
     const int64_t g0 = (int64_t)t0 * hop - n_fft / 2;
@@ -639,7 +654,7 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
         for (int c = 0; c < CSM; ++c) fe[c] = (c < CS && pos[c] >= 0) ? fact * Texp[pos[c]] : 0.0;
 #pragma unroll 4
         for (int k = ka; k < kb; ++k) {
-          const double bk = Tbeta[k - 1];
+          const double bk = Tbeta_at(k - 1);
 #pragma unroll
           for (int c = 0; c < CSM; ++c)
             if (c < CS) pr[c] += fe[c] * bk;
@@ -663,7 +678,7 @@ __global__ __launch_bounds__(256, (RR <= 6 ? 3 : 1)) void k_f0_yin(const float* 
         const int k = k0 + lane;
         nbelow += __popcll(__ballot(k <= kF0Thresholds && !(hm < Tthr[k <= kF0Thresholds ? k : kF0Thresholds])));
       }
-      const double extra = fp.no_trough_prob * Tcum[nbelow];
+      const double extra = fp.no_trough_prob * Tcum_at(nbelow);
 #pragma unroll
       for (int c = 0; c < CSM; ++c)
         if (tr[c] && lane + 64 * c == jm) pr[c] += extra;
@@ -1416,7 +1431,12 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
   const bool ref_shape = fp.hop == 256 && fp.W == 512 && fp.n_fft == 1024 && fp.R == 6 && fp.slots == 6 && fp.n_lag == 329 &&
                          fp.n_tau == 339 && fp.n_tau_pad == 384 && fp.min_period == 10 && fp.max_period == 338 && fp.cap == 168 &&
                          fp.n_bins == 601 && fpb == 8;
-  if (ref_shape) { AFX_YIN_LAUNCH_FR(6, 8, true); return hipGetLastError(); }
+  if (ref_shape) {
+    const size_t lds_ref = yin_lds_i(fp.hop, fp.n_fft, fp.n_tau_pad, fp.slots, fp.cap, 8, true, true).total;
+    hipLaunchKernelGGL((k_f0_yin<6, 6, 8, true>), grid, dim3(256), lds_ref, s, ysig, clips, info, energy, tb, fp, cand_cnt,
+                       cand_vp, cand_bin, cand_prob);
+    return hipGetLastError();
+  }
 #define AFX_YIN_LAUNCH(N) do { if (fpb == 8) AFX_YIN_LAUNCH_F(N, 8); else AFX_YIN_LAUNCH_F(N, 16); } while (0)
   if (need <= 4) AFX_YIN_LAUNCH(4);
   else if (need <= 6) AFX_YIN_LAUNCH(6);
