@@ -243,6 +243,18 @@ def test_f0_failure_drops_the_files_instead_of_reporting_zero_f0(tmp_path):
 def test_windows_bound_host_memory(tmp_path):
     from audio_feature_extraction_amd import parallel
     assert parallel._windows([5, 5, 5, 20, 1], [0, 1, 2, 3, 4], 10) == [[0, 1], [2], [3], [4]]
+    # even shares: 683 equal files under a budget of 300 are three windows of 228 / 228 / 227, not 300 / 300 / 83 (a short
+    # last window costs a whole device pass); the budget still bounds every window, an oversize file is a window of its own
+    assert [len(w) for w in parallel._windows([1] * 683, list(range(683)), 300)] == [228, 228, 227]
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(1, 400, 500).tolist()
+    for budget in (100, 1000, 10 ** 6):
+        wins = parallel._windows(sizes, list(range(500)), budget)
+        assert sum(wins, []) == list(range(500))
+        tot = [sum(sizes[i] for i in w) for w in wins]
+        assert all(t <= budget or len(w) == 1 for t, w in zip(tot, wins))
+        if budget == 1000:
+            assert max(tot) - min(tot) <= 2 * max(sizes)
     files, sums = _write_clips(tmp_path, 30)
     calls = []
     ex, _ = _fake_extractor(2, calls)
