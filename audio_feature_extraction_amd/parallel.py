@@ -192,7 +192,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 80 * 1024
     On the device a worker owns two plans (own stream each): the MFCC / RMS pass of a sub-batch is queued with
     afx_extract_submit on the first and collected only after the pYIN pass of the same sub-batch (afx_f0_batch, second
     plan) has run beside it -- one upload serves both.  ``features_to_extract`` (README.md:141-146) leaves out the passes
-    nobody asked for: without 'f0' no pYIN pass runs (it is ~45x the MFCC pass).
+    nobody asked for: without 'f0' no pYIN pass runs (it is ~30x the MFCC pass).
 
     Error behaviour is the reference's (feature_extractor.py:229-235): a file that cannot be loaded, a clip the
     kernels reject, or a device-level failure while its window is processed is logged and left out; the batch goes on."""
