@@ -385,8 +385,20 @@ size_t f0_yin_lds_bytes(const F0Params& fp) {
 // RR >= lags per lane (fp.R), SS >= trough slots per lane (fp.slots): per-lane arrays are sized by them
 // REF: the reference's shape (22050 Hz, frame_length 1024, C2..C7) compiled in -- periods 10..338, 339 lags in rows of 384,
 // 329 kept, 168 candidates at most, 601 pitch bins: the kernel is short of scalar registers, and offsets become immediates.
-template <int RR, int SS, int FPB, bool REF>
-__global__ __launch_bounds__(256, (REF ? 4 : RR <= 6 ? 3 : 1)) void k_f0_yin(const float* __restrict__ ysig,
+// SH: 0 any shape (from the parameters); 1 the reference's (above; compact LDS layout); 2 the same pitch range at 16 kHz,
+// frame_length 512 (BASELINE configs[2]): periods 7..245, 246 lags in rows of 256, 239 kept, 128 candidates.
+template <int SH> struct YinShape { static constexpr int hop = 0, W = 0, n_fft = 0, R = 0, slots = 0, n_lag = 0, n_tau = 0, n_tau_pad = 0, min_period = 0, max_period = 0, cap = 0, n_bins = 0; };
+template <> struct YinShape<1> { static constexpr int hop = 256, W = 512, n_fft = 1024, R = 6, slots = 6, n_lag = 329, n_tau = 339, n_tau_pad = 384, min_period = 10, max_period = 338, cap = 168, n_bins = 601; };
+template <> struct YinShape<2> { static constexpr int hop = 128, W = 256, n_fft = 512, R = 4, slots = 4, n_lag = 239, n_tau = 246, n_tau_pad = 256, min_period = 7, max_period = 245, cap = 128, n_bins = 601; };
+template <int SH>
+static bool yin_shape_is(const F0Params& fp) {
+  typedef YinShape<SH> Y;
+  return fp.hop == Y::hop && fp.W == Y::W && fp.n_fft == Y::n_fft && fp.R == Y::R && fp.slots == Y::slots && fp.n_lag == Y::n_lag &&
+         fp.n_tau == Y::n_tau && fp.n_tau_pad == Y::n_tau_pad && fp.min_period == Y::min_period && fp.max_period == Y::max_period &&
+         fp.cap == Y::cap && fp.n_bins == Y::n_bins;
+}
+template <int RR, int SS, int FPB, int SH>
+__global__ __launch_bounds__(256, (SH ? 4 : RR <= 6 ? 3 : 1)) void k_f0_yin(const float* __restrict__ ysig,
                                                 const ClipDesc* __restrict__ clips,
                                                 const ClipInfo* __restrict__ info,
                                                 const float* __restrict__ energy,
@@ -407,10 +419,12 @@ __global__ __launch_bounds__(256, (REF ? 4 : RR <= 6 ? 3 : 1)) void k_f0_yin(con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr bool YF = RR <= 6;
   typedef typename std::conditional<YF, float, double>::type ysig_t;
-  const int hop = REF ? 256 : fp.hop, W = REF ? 512 : fp.W, R = REF ? 6 : fp.R, slots = REF ? 6 : fp.slots, n_lag = REF ? 329 : fp.n_lag;
-  const int n_fft = REF ? 1024 : fp.n_fft, n_tau = REF ? 339 : fp.n_tau, n_tau_pad = REF ? 384 : fp.n_tau_pad;
-  const int min_period = REF ? 10 : fp.min_period, max_period = REF ? 338 : fp.max_period, cap = REF ? 168 : fp.cap;
-  const int n_bins = REF ? 601 : fp.n_bins;
+  typedef YinShape<SH> YS;
+  constexpr bool REF = SH == 1, KN = SH != 0;
+  const int hop = KN ? YS::hop : fp.hop, W = KN ? YS::W : fp.W, R = KN ? YS::R : fp.R, slots = KN ? YS::slots : fp.slots, n_lag = KN ? YS::n_lag : fp.n_lag;
+  const int n_fft = KN ? YS::n_fft : fp.n_fft, n_tau = KN ? YS::n_tau : fp.n_tau, n_tau_pad = KN ? YS::n_tau_pad : fp.n_tau_pad;
+  const int min_period = KN ? YS::min_period : fp.min_period, max_period = KN ? YS::max_period : fp.max_period, cap = KN ? YS::cap : fp.cap;
+  const int n_bins = KN ? YS::n_bins : fp.n_bins;
   const YinLds L = yin_lds_i(hop, n_fft, n_tau_pad, slots, cap, FPB, YF, REF);
   static_assert(!REF || 64 + 168 + 84 <= 384, "CP / CB behind the event flags of the D row");
   ysig_t* Y = reinterpret_cast<ysig_t*>(smy);
@@ -1420,23 +1434,21 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
   const int fpb = f0_yin_frames_per_block(fp);
   dim3 grid((max_tmax + fpb - 1) / fpb, n_clips);
   const int need = fp.R > fp.slots ? fp.R : fp.slots;
-#define AFX_YIN_LAUNCH_FR(N, F, REF)                                                                            \
+#define AFX_YIN_LAUNCH_FR(N, F, SH)                                                                             \
   do {                                                                                                         \
-    hipError_t e2 = allow_lds(k_f0_yin<N, N, F, REF>, lds);                                                    \
+    hipError_t e2 = allow_lds(k_f0_yin<N, N, F, SH>, lds);                                                     \
     if (e2 != hipSuccess) return e2;                                                                           \
-    hipLaunchKernelGGL((k_f0_yin<N, N, F, REF>), grid, dim3(256), lds, s, ysig, clips, info, energy, tb, fp, cand_cnt, \
+    hipLaunchKernelGGL((k_f0_yin<N, N, F, SH>), grid, dim3(256), lds, s, ysig, clips, info, energy, tb, fp, cand_cnt, \
                        cand_vp, cand_bin, cand_prob);                                                          \
   } while (0)
-#define AFX_YIN_LAUNCH_F(N, F) AFX_YIN_LAUNCH_FR(N, F, false)
-  const bool ref_shape = fp.hop == 256 && fp.W == 512 && fp.n_fft == 1024 && fp.R == 6 && fp.slots == 6 && fp.n_lag == 329 &&
-                         fp.n_tau == 339 && fp.n_tau_pad == 384 && fp.min_period == 10 && fp.max_period == 338 && fp.cap == 168 &&
-                         fp.n_bins == 601 && fpb == 8;
-  if (ref_shape) {
+#define AFX_YIN_LAUNCH_F(N, F) AFX_YIN_LAUNCH_FR(N, F, 0)
+  if (yin_shape_is<1>(fp) && fpb == 8) {
     const size_t lds_ref = yin_lds_i(fp.hop, fp.n_fft, fp.n_tau_pad, fp.slots, fp.cap, 8, true, true).total;
-    hipLaunchKernelGGL((k_f0_yin<6, 6, 8, true>), grid, dim3(256), lds_ref, s, ysig, clips, info, energy, tb, fp, cand_cnt,
+    hipLaunchKernelGGL((k_f0_yin<6, 6, 8, 1>), grid, dim3(256), lds_ref, s, ysig, clips, info, energy, tb, fp, cand_cnt,
                        cand_vp, cand_bin, cand_prob);
     return hipGetLastError();
   }
+  if (yin_shape_is<2>(fp) && fpb == 16) { AFX_YIN_LAUNCH_FR(4, 16, 2); return hipGetLastError(); }
 #define AFX_YIN_LAUNCH(N) do { if (fpb == 8) AFX_YIN_LAUNCH_F(N, 8); else AFX_YIN_LAUNCH_F(N, 16); } while (0)
   if (need <= 4) AFX_YIN_LAUNCH(4);
   else if (need <= 6) AFX_YIN_LAUNCH(6);
@@ -1490,6 +1502,7 @@ hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInf
   else
 #endif
   if (ref_shape) AFX_VIT_LAUNCH(0, 601, 25);
+  else if (fp.n_bins == 601 && fp.band == 15) AFX_VIT_LAUNCH(0, 601, 15);       // the same pitch range at hop / sr = 128 / 16000
   else AFX_VIT_LAUNCH(0, 0, 0);
 #undef AFX_VIT_LAUNCH
   if ((e = hipGetLastError()) != hipSuccess) return e;
