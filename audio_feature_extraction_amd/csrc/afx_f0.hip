@@ -386,10 +386,12 @@ size_t f0_yin_lds_bytes(const F0Params& fp) {
 // REF: the reference's shape (22050 Hz, frame_length 1024, C2..C7) compiled in -- periods 10..338, 339 lags in rows of 384,
 // 329 kept, 168 candidates at most, 601 pitch bins: the kernel is short of scalar registers, and offsets become immediates.
 // SH: 0 any shape (from the parameters); 1 the reference's (above; compact LDS layout); 2 the same pitch range at 16 kHz,
-// frame_length 512 (BASELINE configs[2]): periods 7..245, 246 lags in rows of 256, 239 kept, 128 candidates.
+// frame_length 512 (BASELINE configs[2]): periods 7..245, 246 lags in rows of 256, 239 kept, 128 candidates; 3 the same at
+// 44.1 kHz, frame_length 2048 (configs[4]): periods 21..675, 676 lags in rows of 704, 655 kept, 336 candidates.
 template <int SH> struct YinShape { static constexpr int hop = 0, W = 0, n_fft = 0, R = 0, slots = 0, n_lag = 0, n_tau = 0, n_tau_pad = 0, min_period = 0, max_period = 0, cap = 0, n_bins = 0; };
 template <> struct YinShape<1> { static constexpr int hop = 256, W = 512, n_fft = 1024, R = 6, slots = 6, n_lag = 329, n_tau = 339, n_tau_pad = 384, min_period = 10, max_period = 338, cap = 168, n_bins = 601; };
 template <> struct YinShape<2> { static constexpr int hop = 128, W = 256, n_fft = 512, R = 4, slots = 4, n_lag = 239, n_tau = 246, n_tau_pad = 256, min_period = 7, max_period = 245, cap = 128, n_bins = 601; };
+template <> struct YinShape<3> { static constexpr int hop = 512, W = 1024, n_fft = 2048, R = 11, slots = 11, n_lag = 655, n_tau = 676, n_tau_pad = 704, min_period = 21, max_period = 675, cap = 336, n_bins = 601; };
 template <int SH>
 static bool yin_shape_is(const F0Params& fp) {
   typedef YinShape<SH> Y;
@@ -398,7 +400,7 @@ static bool yin_shape_is(const F0Params& fp) {
          fp.cap == Y::cap && fp.n_bins == Y::n_bins;
 }
 template <int RR, int SS, int FPB, int SH>
-__global__ __launch_bounds__(256, (SH ? 4 : RR <= 6 ? 3 : 1)) void k_f0_yin(const float* __restrict__ ysig,
+__global__ __launch_bounds__(256, ((SH == 1 || SH == 2) ? 4 : RR <= 6 ? 3 : 1)) void k_f0_yin(const float* __restrict__ ysig,
                                                 const ClipDesc* __restrict__ clips,
                                                 const ClipInfo* __restrict__ info,
                                                 const float* __restrict__ energy,
@@ -1449,6 +1451,7 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
     return hipGetLastError();
   }
   if (yin_shape_is<2>(fp) && fpb == 16) { AFX_YIN_LAUNCH_FR(4, 16, 2); return hipGetLastError(); }
+  if (yin_shape_is<3>(fp) && fpb == 16) { AFX_YIN_LAUNCH_FR(11, 16, 3); return hipGetLastError(); }
 #define AFX_YIN_LAUNCH(N) do { if (fpb == 8) AFX_YIN_LAUNCH_F(N, 8); else AFX_YIN_LAUNCH_F(N, 16); } while (0)
   if (need <= 4) AFX_YIN_LAUNCH(4);
   else if (need <= 6) AFX_YIN_LAUNCH(6);
