@@ -14,6 +14,8 @@ traffic.  Two deployment shapes share the partition/gather helpers here:
 """
 from __future__ import annotations
 
+import queue
+import sys
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -285,8 +287,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 80 * 1024
         return packed, rest, decoded
 
     timeline: List[Any] = []                                      # (lane, clips, t_begin, t_uploaded, t_f0_done, t_collected) per sub-batch
-    import queue as _queue
-    finished: Any = _queue.SimpleQueue()                          # index lists of sub-batches whose results are in the arrays
+    finished: Any = queue.SimpleQueue()                          # index lists of sub-batches whose results are in the arrays
     recs: List[Any] = [None] * n
 
     def run_group(plans, cur, buf, offs, lens, fmt, dev):
@@ -386,42 +387,44 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 80 * 1024
     # The calling thread builds the result dicts of finished sub-batches while the workers drive the device (55 Python floats
     # and four lists per file: 35-50 ms for 8192 files if left to the end).  The workers need the interpreter only for
     # microseconds between two native calls, but would wait a whole switch interval (5 ms) for it: shortened for the duration.
-    import sys as _sys
-    old_iv = _sys.getswitchinterval()
-    _sys.setswitchinterval(2e-4)
+    def delivered(i):
+        # fewer than nine frames fails the MFCC group only (the width-9 delta); extract_energy has its statistics
+        return status[i] == _native.CLIP_OK or ("mfcc" not in want and status[i] == _native.CLIP_TOO_SHORT and
+                                                 nsamp[i] >= 2 and nframes[i] >= 1)
+
+    from .core.feature_extractor import AudioFeatureExtractor as _Stock
+    stock = (getattr(type(extractor), "_stats_to_dicts", None) is _Stock._stats_to_dicts and
+             getattr(type(extractor), "_f0_to_dict", None) is _Stock._f0_to_dict)      # else: the extractor's own methods, at the end
+    K4 = 4 * K
+
+    def build(i):                                                     # what _stats_to_dicts / _f0_to_dict build, key for key
+        row, rec = stats[i].tolist(), {"file_path": str(files[i])}
+        if want_f0:
+            q = f0s[i].tolist()
+            rec["f0_mean"], rec["f0_std"], rec["f0_missing_rate"], rec["f0_quality"] = q[0], q[1], q[2], q[3]
+        if "mfcc" in want:
+            rec["mfcc_mean"], rec["mfcc_std"] = row[0:K], row[K:2 * K]
+            rec["mfcc_delta_mean"], rec["mfcc_delta2_mean"] = row[2 * K:3 * K], row[3 * K:K4]
+        if "energy" in want:
+            rec["energy_mean"], rec["energy_std"], rec["energy_range"] = row[K4], row[K4 + 1], row[K4 + 2]
+        return rec
+
+    def drain(block):
+        try:
+            cur = finished.get(timeout=0.002) if block else finished.get_nowait()
+        except queue.Empty:
+            return False
+        if stock:
+            for i in cur:
+                if errors[i] is None and delivered(i):
+                    recs[i] = build(i)
+        return True
+
+    old_iv = sys.getswitchinterval()
+    sys.setswitchinterval(2e-4)
     try:
         for t in threads:
             t.start()
-        K4 = 4 * K
-        def build(i):
-            row, rec = stats[i].tolist(), {"file_path": str(files[i])}
-            if want_f0:
-                q = f0s[i].tolist()
-                rec["f0_mean"], rec["f0_std"], rec["f0_missing_rate"], rec["f0_quality"] = q[0], q[1], q[2], q[3]
-            if "mfcc" in want:
-                rec["mfcc_mean"], rec["mfcc_std"] = row[0:K], row[K:2 * K]
-                rec["mfcc_delta_mean"], rec["mfcc_delta2_mean"] = row[2 * K:3 * K], row[3 * K:K4]
-            if "energy" in want:
-                rec["energy_mean"], rec["energy_std"], rec["energy_range"] = row[K4], row[K4 + 1], row[K4 + 2]
-            return rec
-        stock = True
-        try:
-            from .core.feature_extractor import AudioFeatureExtractor as _A
-            stock = (getattr(type(extractor), "_stats_to_dicts", None) is _A._stats_to_dicts and
-                     getattr(type(extractor), "_f0_to_dict", None) is _A._f0_to_dict)
-        except Exception:
-            stock = False
-        def drain(block):
-            try:
-                cur = finished.get(timeout=0.002) if block else finished.get_nowait()
-            except _queue.Empty:
-                return False
-            if stock:
-                for i in cur:
-                    if errors[i] is None and (status[i] == _native.CLIP_OK or
-                                              ("mfcc" not in want and status[i] == _native.CLIP_TOO_SHORT and nsamp[i] >= 2 and nframes[i] >= 1)):
-                        recs[i] = build(i)
-            return True
         while any(t.is_alive() for t in threads):
             drain(True)
         while drain(False):
@@ -429,7 +432,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 80 * 1024
         for t in threads:
             t.join()
     finally:
-        _sys.setswitchinterval(old_iv)
+        sys.setswitchinterval(old_iv)
     win_pool.shutdown()
     pool.shutdown()
 
@@ -439,9 +442,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 80 * 1024
     for i, f in enumerate(files):
         name = getattr(f, "name", str(f))
         err = errors[i]
-        # fewer than nine frames fails the MFCC group only (the width-9 delta); extract_energy has its statistics
-        energy_ok = ("mfcc" not in want and status[i] == _native.CLIP_TOO_SHORT and nsamp[i] >= 2 and nframes[i] >= 1)
-        if err is None and status[i] != _native.CLIP_OK and not energy_ok:
+        if err is None and not delivered(i):
             err = _status_error(int(status[i]), "extract_features", int(nframes[i]))
             log.error(f"特徵提取失敗: {str(err)}")
         if err is not None:
