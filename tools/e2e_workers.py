@@ -1,3 +1,4 @@
+"""End-to-end time of process_files against workers per GPU and window size: python tools/e2e_workers.py n_files"""
 import os, sys, tempfile, time, logging
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
