@@ -137,6 +137,25 @@ class _DevPool:
             old.free()
 
 
+_switch_lock = threading.Lock()
+_switch_state = [0, 0.0]               # process_files calls in flight, the interpreter's own switch interval
+
+
+def _fast_switch(on: bool):
+    """The interpreter's thread switch interval at 0.2 ms while any process_files call runs (first in saves it, last out
+    restores it: calls may overlap)."""
+    with _switch_lock:
+        if on:
+            if _switch_state[0] == 0:
+                _switch_state[1] = sys.getswitchinterval()
+                sys.setswitchinterval(2e-4)
+            _switch_state[0] += 1
+        else:
+            _switch_state[0] -= 1
+            if _switch_state[0] == 0:
+                sys.setswitchinterval(_switch_state[1])
+
+
 LAST_TIMING: Dict[str, Any] = {}     # seconds per phase of the last process_files call (developer aid)
 WORKERS_PER_GPU = 3     # sub-batches in flight per GPU (own context / stream / thread): copies, the bandwidth-bound
                         # kernels and the host round trip of one hide under the frame kernel of another
@@ -420,8 +439,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 80 * 1024
                     recs[i] = build(i)
         return True
 
-    old_iv = sys.getswitchinterval()
-    sys.setswitchinterval(2e-4)
+    _fast_switch(True)
     try:
         for t in threads:
             t.start()
@@ -432,7 +450,7 @@ def process_files(extractor, files: Sequence, max_batch_samples: int = 80 * 1024
         for t in threads:
             t.join()
     finally:
-        sys.setswitchinterval(old_iv)
+        _fast_switch(False)
     win_pool.shutdown()
     pool.shutdown()
 
