@@ -41,7 +41,8 @@ struct F0Tables {
   const double* bfact;    // [cap + 1] (1 - e^-2) / (1 - e^-2n)  (scipy.stats.boltzmann.pmf normaliser)
   const double* bexp;     // [cap + 1] e^-2k
   const double* lt;       // [2][2 * band + 1][2 * band + 1] log(switch * local[row class][d] + tiny)
-  const double* ltw;      // [2 * band + 1][2] the interior row as the band walk meets it: {stay, switch} of entry 2 band - e
+  const double* ltw;      // [2][2 * band + 1] the interior row as the band walk meets it: entry 2 band - e; stay row, then switch row
+                          // (contiguous, so that the walk's scalar loads take several weights at once)
   const double* freqs;    // [n_bins] fmin * 2^(b / 120)
 };
 

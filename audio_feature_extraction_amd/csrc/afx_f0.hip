@@ -924,7 +924,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   const double* LTs = LT;                               // stay (the switch table is k_f0_backtrack's business)
   // the interior row class (every source at least `band` bins from both range ends) is read through the scalar
   // cache: its index is wave-uniform, so the band walk's weights cost no LDS traffic and no vector registers
-  cdouble_k* const kk = as_constant(tb.ltw);           // {stay, switch} per band entry, in walk order
+  cdouble_k* const kk = as_constant(static_cast<const double*>(__builtin_assume_aligned(tb.ltw, 64)));   // the stay weights in walk order (hipMalloc'ed)
 
   // Value columns in LDS, two in rotation.  A column is kept as
   //   main[v][band + b]  b = -band .. nb - 1 + band: the value of (voicing v, bin b) when b is an interior-class
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
           const double* p1 = m1 + jc;
 #pragma unroll 4
           for (int e = 0; e < width; ++e) {
-            const double ws = kk[2 * e];
+            const double ws = kk[e];
             bv = fmax(bv, p0[e] + ws);
             bu = fmax(bu, p1[e] + ws);
           }

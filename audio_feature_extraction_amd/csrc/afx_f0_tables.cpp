@@ -90,7 +90,7 @@ bool build_f0_tables(int sr, int n_fft, int hop, double fmin, double fmax, HostF
   }
   t.ltw.resize((size_t)2 * width);
   for (int e = 0; e < width; ++e)
-    for (int v = 0; v < 2; ++v) t.ltw[2 * e + v] = t.lt[(size_t)v * NC * width + (2 * p.band - e)];
+    for (int v = 0; v < 2; ++v) t.ltw[(size_t)v * width + e] = t.lt[(size_t)v * NC * width + (2 * p.band - e)];
   t.freqs.resize(p.n_bins);
   for (int b = 0; b < p.n_bins; ++b) t.freqs[b] = fmin * std::pow(2.0, (double)b / p.bins_per_octave);
   return true;
