@@ -854,7 +854,8 @@ static int f0_chunk(afx_plan* pl, const void* d_samples, int fmt, const int64_t*
   if ((rc = ensure(pl->f0_cnt, (size_t)frames * sizeof(int32_t))) != AFX_OK) return rc;
   if ((rc = ensure(pl->f0_vp, (size_t)frames * sizeof(double))) != AFX_OK) return rc;
   if ((rc = ensure(pl->f0_bin, f0_cand_bins_bytes(fp, frames))) != AFX_OK) return rc;
-  if ((rc = ensure(pl->f0_prob, f0_cand_prob_bytes(fp, frames))) != AFX_OK) return rc;
+  const bool dump_obs = dev_env().f0_dump != nullptr;        // the linear probabilities are kept for the diagnostic dump only
+  if (dump_obs && (rc = ensure(pl->f0_prob, f0_cand_prob_bytes(fp, frames))) != AFX_OK) return rc;
   if ((rc = ensure(pl->f0_ptr, f0_vrows_bytes(fp, frames))) != AFX_OK) return rc;
   if ((rc = ensure(pl->f0_best, (size_t)frames * sizeof(VitBest))) != AFX_OK) return rc;
   if ((rc = ensure(pl->f0_lprob, f0_cand_prob_bytes(fp, frames))) != AFX_OK) return rc;
@@ -892,11 +893,11 @@ static int f0_chunk(afx_plan* pl, const void* d_samples, int fmt, const int64_t*
   HIP_TRY(launch_f0_prep(s, d_samples, d_clips, d_info, (float*)pl->f0_ysig.p, n, max_len, kp));
   HIP_TRY(launch_f0_energy(s, (const float*)pl->f0_ysig.p, d_clips, d_info, (float*)pl->f0_energy.p, n, pl->max_tmax, fp));
   HIP_TRY(launch_f0_yin(s, (const float*)pl->f0_ysig.p, d_clips, d_info, (const float*)pl->f0_energy.p, pl->f0_dt, fp,
-                        (int32_t*)pl->f0_cnt.p, (double*)pl->f0_vp.p, (int16_t*)pl->f0_bin.p, (double*)pl->f0_prob.p,
-                        n, pl->max_tmax));
-  HIP_TRY(launch_f0_viterbi(s, d_clips, d_info, pl->f0_dt, fp, (const int32_t*)pl->f0_cnt.p, (const double*)pl->f0_vp.p,
-                            (const int16_t*)pl->f0_bin.p, (const double*)pl->f0_prob.p, (double*)pl->f0_lprob.p,
-                            (double*)pl->f0_lu.p, frames, (double*)pl->f0_ptr.p, (VitBest*)pl->f0_best.p,
+                        (int32_t*)pl->f0_cnt.p, (double*)pl->f0_vp.p, (int16_t*)pl->f0_bin.p,
+                        dump_obs ? (double*)pl->f0_prob.p : nullptr, (double*)pl->f0_lprob.p, (double*)pl->f0_lu.p, n, pl->max_tmax));
+  HIP_TRY(launch_f0_viterbi(s, d_clips, d_info, pl->f0_dt, fp, (const int32_t*)pl->f0_cnt.p,
+                            (const int16_t*)pl->f0_bin.p, (const double*)pl->f0_lprob.p,
+                            (const double*)pl->f0_lu.p, (double*)pl->f0_ptr.p, (VitBest*)pl->f0_best.p,
                             (uint16_t*)pl->f0_states.p, (double*)pl->f0_stats.p, d_f0, (const int64_t*)pl->f0_offs.p, n));
   std::vector<ClipInfo> h_info(n);
   HIP_TRY(hipMemcpyAsync(out_stats, pl->f0_stats.p, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -74,12 +74,12 @@ hipError_t launch_f0_energy(hipStream_t s, const float* ysig, const ClipDesc* cl
                             float* energy, int n_clips, int max_tmax, const F0Params& fp);
 hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips, const ClipInfo* info,
                          const float* energy, const F0Tables& tb, const F0Params& fp,
-                         int32_t* cand_cnt, double* cand_vp, int16_t* cand_bin, double* cand_prob,
-                         int n_clips, int max_tmax);
+                         int32_t* cand_cnt, double* cand_vp, int16_t* cand_bin, double* cand_prob /* nullable: diagnostics */,
+                         double* cand_lp, double* cand_lu, int n_clips, int max_tmax);
 hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const F0Tables& tb,
-                             const F0Params& fp, const int32_t* cand_cnt, const double* cand_vp,
-                             const int16_t* cand_bin, const double* cand_prob, double* cand_lp, double* cand_lu,
-                             int64_t frames, double* vrows, VitBest* vbest,
+                             const F0Params& fp, const int32_t* cand_cnt,
+                             const int16_t* cand_bin, const double* cand_lp, const double* cand_lu,
+                             double* vrows, VitBest* vbest,
                              uint16_t* states, double* out_stats, double* out_f0, const int64_t* f0_offsets,
                              int n_clips);
 

@@ -7,8 +7,8 @@
 //   k_f0_energy   one lane per frame: e[W + tau] - e[tau] of the float32 running sum of squares
 //   k_f0_yin      one wave per frame: autocorrelation (direct, float64), difference function,
 //                 cumulative-mean normalisation, troughs, threshold/Boltzmann/Beta probabilities,
-//                 parabolic refinement, pitch bins -> a sparse observation column per frame
-//   k_f0_logs     the log observation values the Viterbi pass scatters (kept out of its step loop)
+//                 parabolic refinement, pitch bins -> a sparse observation column per frame, stored as the
+//                 logs the Viterbi pass scatters
 //   k_f0_viterbi  one workgroup per clip: log-domain Viterbi over 2 x n_bins states with the banded
 //                 transition matrix -- value-only forward pass, one barrier per step, every value
 //                 column kept
@@ -408,7 +408,9 @@ __global__ __launch_bounds__(256, ((SH == 1 || SH == 2) ? 4 : RR <= 6 ? 3 : 1)) 
                                                 int32_t* __restrict__ cand_cnt,
                                                 double* __restrict__ cand_vp,
                                                 int16_t* __restrict__ cand_bin,
-                                                double* __restrict__ cand_prob) {
+                                                double* __restrict__ cand_prob,
+                                                double* __restrict__ cand_lp,
+                                                double* __restrict__ cand_lu) {
   extern __shared__ double smy[];
   const int clip = blockIdx.y;
   const ClipInfo ci = info[clip];
@@ -738,7 +740,8 @@ __global__ __launch_bounds__(256, ((SH == 1 || SH == 2) ? 4 : RR <= 6 ? 3 : 1)) 
           const bool keep = (j == cnt - 1) || CB[j + 1] != b;
           const double pj = CP[j];
           cand_bin[slot * cap + j] = (int16_t)(keep ? b : -1);
-          cand_prob[slot * cap + j] = pj;
+          cand_lp[slot * cap + j] = log(pj + fp.tiny);              // what the Viterbi pass scatters (round 2: a pass of its own)
+          if (cand_prob) cand_prob[slot * cap + j] = pj;            // diagnostics only (AFX_F0_DUMP)
           if (keep && b >= 0 && b < n_bins) val[m] = pj;
         }
       }
@@ -757,9 +760,14 @@ __global__ __launch_bounds__(256, ((SH == 1 || SH == 2) ? 4 : RR <= 6 ? 3 : 1)) 
       }
       F0_WAVE_SYNC();
     }
-    if (lane == 0) {
-      cand_cnt[slot] = cnt;
-      cand_vp[slot] = vp < 0.0 ? 0.0 : (vp > 1.0 ? 1.0 : vp);
+    {
+      const double vpc = vp < 0.0 ? 0.0 : (vp > 1.0 ? 1.0 : vp);
+      const double lu = log((1.0 - vpc) / (double)n_bins + fp.tiny);   // the unvoiced bins' common log observation
+      if (lane == 0) {
+        cand_cnt[slot] = cnt;
+        cand_vp[slot] = vpc;
+        cand_lu[slot] = lu;
+      }
     }
     stamp(6);
   }
@@ -803,26 +811,6 @@ __host__ __device__ inline VitLds vit_lds(int n_bins, int band_) {
   return L;
 }
 size_t f0_viterbi_lds_bytes(const F0Params& fp) { return vit_lds(fp.n_bins, fp.band).total; }
-
-// k_f0_logs: the log observation values the Viterbi pass scatters -- log(p + tiny) per candidate and the unvoiced
-// bins' common log((1 - voiced_prob) / n_bins + tiny) -- one wave per frame slot.  Kept out of the Viterbi step
-// loop, where a wave's instruction count is the critical path.
-constexpr int kLogsPerWave = 8;
-__global__ __launch_bounds__(256) void k_f0_logs(const int32_t* __restrict__ cand_cnt, const double* __restrict__ cand_vp,
-                                                 const double* __restrict__ cand_prob, double* __restrict__ cand_lp,
-                                                 double* __restrict__ cand_lu, int64_t frames, F0Params fp) {
-  // a wave takes kLogsPerWave consecutive frame slots (one each made 864 000 waves of a few instructions for 1000 clips)
-  const int lane = threadIdx.x & 63;
-  const int64_t f0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kLogsPerWave;
-  for (int u = 0; u < kLogsPerWave; ++u) {
-    const int64_t f = f0 + u;
-    if (f >= frames) return;
-    int cnt = cand_cnt[f];                               // slots between clips hold nothing: any value is harmless
-    cnt = cnt < 0 ? 0 : (cnt > fp.cap ? fp.cap : cnt);
-    for (int i = lane; i < cnt; i += 64) cand_lp[f * fp.cap + i] = log(cand_prob[f * fp.cap + i] + fp.tiny);
-    if (lane == 0) cand_lu[f] = log((1.0 - cand_vp[f]) / (double)fp.n_bins + fp.tiny);
-  }
-}
 
 // MODE 0: production; 1: the timing-only ablation bits of AFX_F0_DEBUG honoured; 2: per-phase cycle stamps as well.
 // NBT / BANDT: n_bins and band compiled in (0: taken from the parameters) -- the step loop is short of scalar registers,
@@ -949,7 +937,7 @@ __global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* _
   // Observation columns: three LDS columns in rotation, all log(0) except where a step's candidates were
   // scattered.  During step t a thread scatters its candidate of step t + 1 (loaded a step earlier) and takes
   // back the one it scattered for step t - 1; the three touch different columns, so the step's one barrier
-  // orders everything.  The logs come from k_f0_logs.
+  // orders everything.  The logs come from k_f0_yin.
   auto load_cand = [&](int t, int& bin, double& lp, double& lu_) {
     const int64_t ns = cd.frame_base + t;
     const int cnt = cand_cnt[ns];
@@ -1431,7 +1419,7 @@ hipError_t launch_f0_energy(hipStream_t s, const float* ysig, const ClipDesc* cl
 hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips, const ClipInfo* info,
                          const float* energy, const F0Tables& tb, const F0Params& fp,
                          int32_t* cand_cnt, double* cand_vp, int16_t* cand_bin, double* cand_prob,
-                         int n_clips, int max_tmax) {
+                         double* cand_lp, double* cand_lu, int n_clips, int max_tmax) {
   const size_t lds = f0_yin_lds_bytes(fp);
   const int fpb = f0_yin_frames_per_block(fp);
   dim3 grid((max_tmax + fpb - 1) / fpb, n_clips);
@@ -1441,13 +1429,13 @@ hipError_t launch_f0_yin(hipStream_t s, const float* ysig, const ClipDesc* clips
     hipError_t e2 = allow_lds(k_f0_yin<N, N, F, SH>, lds);                                                     \
     if (e2 != hipSuccess) return e2;                                                                           \
     hipLaunchKernelGGL((k_f0_yin<N, N, F, SH>), grid, dim3(256), lds, s, ysig, clips, info, energy, tb, fp, cand_cnt, \
-                       cand_vp, cand_bin, cand_prob);                                                          \
+                       cand_vp, cand_bin, cand_prob, cand_lp, cand_lu);                                        \
   } while (0)
 #define AFX_YIN_LAUNCH_F(N, F) AFX_YIN_LAUNCH_FR(N, F, 0)
   if (yin_shape_is<1>(fp) && fpb == 8) {
     const size_t lds_ref = yin_lds_i(fp.hop, fp.n_fft, fp.n_tau_pad, fp.slots, fp.cap, 8, true, true).total;
     hipLaunchKernelGGL((k_f0_yin<6, 6, 8, 1>), grid, dim3(256), lds_ref, s, ysig, clips, info, energy, tb, fp, cand_cnt,
-                       cand_vp, cand_bin, cand_prob);
+                       cand_vp, cand_bin, cand_prob, cand_lp, cand_lu);
     return hipGetLastError();
   }
   if (yin_shape_is<2>(fp) && fpb == 16) { AFX_YIN_LAUNCH_FR(4, 16, 2); return hipGetLastError(); }
@@ -1483,13 +1471,11 @@ static hipError_t launch_f0_backtrack(hipStream_t s, const ClipDesc* clips, cons
 }
 
 hipError_t launch_f0_viterbi(hipStream_t s, const ClipDesc* clips, const ClipInfo* info, const F0Tables& tb,
-                             const F0Params& fp, const int32_t* cand_cnt, const double* cand_vp,
-                             const int16_t* cand_bin, const double* cand_prob, double* cand_lp, double* cand_lu,
-                             int64_t frames, double* vrows, VitBest* vbest,
+                             const F0Params& fp, const int32_t* cand_cnt,
+                             const int16_t* cand_bin, const double* cand_lp, const double* cand_lu,
+                             double* vrows, VitBest* vbest,
                              uint16_t* states, double* out_stats, double* out_f0, const int64_t* f0_offsets,
                              int n_clips) {
-  hipLaunchKernelGGL(k_f0_logs, dim3((unsigned)((frames + 4 * kLogsPerWave - 1) / (4 * kLogsPerWave))), dim3(256), 0, s, cand_cnt, cand_vp, cand_prob, cand_lp,
-                     cand_lu, frames, fp);
   const size_t lds = f0_viterbi_lds_bytes(fp);
   hipError_t e;
 #define AFX_VIT_LAUNCH(MODE, NBT, BANDT)                                                                              \
