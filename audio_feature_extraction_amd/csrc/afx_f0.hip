@@ -816,7 +816,9 @@ size_t f0_viterbi_lds_bytes(const F0Params& fp) { return vit_lds(fp.n_bins, fp.b
 // NBT / BANDT: n_bins and band compiled in (0: taken from the parameters) -- the step loop is short of scalar registers,
 // and with the reference's shape (601 bins, band 25) as constants the column strides and table offsets are immediates.
 template <int MODE, int NBT, int BANDT>
-__global__ __launch_bounds__(kVitThreads, 6) void k_f0_viterbi(const ClipDesc* __restrict__ clips,
+// (eight waves per SIMD asked for, i.e. at most 64 VGPRs: two 10-wave workgroups per CU need six, but above 64 registers the
+// kernel runs as if it had the CU to itself -- 68 VGPRs: 23.1 -> 26.2 ms, profiles/r03_ab_runs.txt)
+__global__ __launch_bounds__(kVitThreads, 8) void k_f0_viterbi(const ClipDesc* __restrict__ clips,
                                                                const ClipInfo* __restrict__ info,
                                                                F0Tables tb, F0Params fp,
                                                                const int32_t* __restrict__ cand_cnt,
